@@ -1,0 +1,142 @@
+/*
+ * moonsr.h — C ABI of libmoonsr_hip.so, the MI355X (gfx950) implementation of the tiled DEM
+ * super-resolution inference path of AntoineRichard/MoonSuperResolution.
+ *
+ * The reference has NO native interface: its device boundary is the duck-typed Python call
+ *     pred = self.model(np.array(batch), training=False)        (process_full_tiles.py:338)
+ * on a Keras model built by GauGAN(image_size, batch_size, latent_dim) (process_full_tiles.py:28,
+ * spade/models/model.py:340-380) — and its stitcher is NumPy (process_full_tiles.py:363-414).
+ * This header is what a binding for that path would bind; INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no torch / numpy types.
+ *  - every function returns 0 on success or a negative msr_status; msr_last_error() gives the text.
+ *  - tensors are NHWC float32; "dev" pointers are HIP device pointers owned by the CALLER.  The
+ *    library owns only the weights and the workspace inside the handle.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are asynchronous
+ *    on that stream; a handle is not re-entrant.
+ *  - there is NO CPU fallback: if no gfx950 device is usable msr_create fails with MSR_ERR_DEVICE.
+ */
+#ifndef MOONSR_H
+#define MOONSR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSR_ABI_VERSION 1
+
+typedef enum {
+    MSR_OK = 0,
+    MSR_ERR_INVALID = -1,   /* bad argument / shape (the reference raises ValueError / assert) */
+    MSR_ERR_DEVICE = -2,    /* HIP error or no usable device */
+    MSR_ERR_STATE = -3,     /* call out of order (e.g. forward before all weights are loaded) */
+    MSR_ERR_NOMEM = -4
+} msr_status;
+
+/* Generator families of the reference. */
+typedef enum {
+    MSR_GAUGAN = 0,        /* GauGAN.call        spade/models/model.py:564-567  z = mean + exp(var/2)*eps */
+    MSR_GAUGAN_NO_KL = 1,  /* GauGAN_no_KL.call  spade/models/model.py:265-267  z = mean + var          */
+    MSR_CNN = 2,           /* CNNSpade.call      spade/models/model.py:789-791  z = mean + var          */
+    MSR_PIX2PIX = 3        /* Pix2Pix().generator  pix2pix.py:88-108 (image_size fixed to 256)            */
+} msr_variant;
+
+typedef struct {
+    int32_t image_size;  /* S: generator input/output side, power of two >= 64 (GauGAN(image_size, ...)) */
+    int32_t batch_size;  /* B: patches per call; baked in like the reference's sampler (sampling.py:13-15) */
+    int32_t latent_dim;  /* 256 in every reference script (process_full_tiles.py:28) */
+    int32_t variant;     /* msr_variant */
+    int32_t device;      /* HIP device ordinal */
+    int32_t flags;       /* reserved, 0 */
+} msr_config;
+
+typedef struct msr_handle msr_handle;
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+int msr_abi_version(void);
+/* Replaces: GauGAN(image_size, batch_size, latent_dim) + .compile()  (process_full_tiles.py:28-29). */
+int msr_create(const msr_config* cfg, msr_handle** out);
+int msr_destroy(msr_handle* h);
+/* Text of the last error on this handle (h == NULL: last error of a failed msr_create). */
+const char* msr_last_error(const msr_handle* h);
+
+/* ---- weights --------------------------------------------------------------------------------- */
+/* Replaces: gaugan.load(path+'generator', ..., path+'encoder')  (process_full_tiles.py:30,
+ * model.py:607-610).  `host` is a HOST float32 array in the reference's own layout: conv kernels
+ * HWIO [kh,kw,Cin,Cout], Conv2DTranspose kernels [kh,kw,Cout,Cin], dense [in,out]; names as listed
+ * by moonsuperresolution_amd.weights.weight_shapes().  The library re-lays them out for its kernels. */
+int msr_load_weight(msr_handle* h, const char* name, const float* host, const int64_t* shape, int32_t rank);
+/* Number of weights the variant expects / has received so far. */
+int msr_weight_count(const msr_handle* h, int32_t* expected, int32_t* loaded);
+/* Name of the i-th expected weight (NULL if out of range) and its shape. */
+const char* msr_weight_name(const msr_handle* h, int32_t i, int64_t* shape4, int32_t* rank);
+
+/* ---- the generator(call) --------------------------------------------------------------------- */
+/* Replaces: self.model(np.array(batch), training=False)  (process_full_tiles.py:338).
+ *   in_dev   [batch, S, S, 2]  channel 0 = ortho, 1 = low-res DEM, values in [-0.5, 0.5]
+ *   eps_dev  [batch, latent]   the sampler's N(0,1) draw (sampling.py:13-15); required for
+ *                              MSR_GAUGAN, ignored otherwise
+ *   out_dev  [batch, S, S, 1]
+ * batch must equal cfg.batch_size (the reference's sampler enforces the same). */
+int msr_forward(msr_handle* h, const float* in_dev, const float* eps_dev, float* out_dev, int32_t batch,
+                void* stream);
+/* Latent z [batch, latent] of the last msr_forward (debug / parity aid), copied to a device buffer. */
+int msr_last_latent(msr_handle* h, float* z_dev, void* stream);
+
+/* ---- tiler / stitcher ------------------------------------------------------------------------ */
+/* Replaces getPatch + normalize for a whole tile (process_full_tiles.py:269-311, 453-457).
+ * For every patch origin (ox[i], oy[i]) (padded-canvas coordinates, int32 on device):
+ *   valid[i]   = no pixel <= no_value in either raster             (uint8)
+ *   minmax[i]  = {img_min, img_max, dem_min, dem_max}               (float32 x4)
+ * img_dev / dem_dev are the padded float32 rasters [rows, cols] (pitch = cols). */
+int msr_patch_stats(msr_handle* h, const float* img_dev, const float* dem_dev, int32_t rows, int32_t cols,
+                    const int32_t* ox_dev, const int32_t* oy_dev, int32_t n, float no_value,
+                    uint8_t* valid_dev, float* minmax_dev, void* stream);
+/* Writes normalised patches [n, S, S, 2] for the given origins; origin (-1,-1) = the all-zero padding
+ * patch of process_full_tiles.py:468-474. */
+int msr_extract_patches(msr_handle* h, const float* img_dev, const float* dem_dev, int32_t rows, int32_t cols,
+                        const int32_t* ox_dev, const int32_t* oy_dev, const float* minmax_dev, int32_t n,
+                        float* out_dev, void* stream);
+/* Replaces processBatch's "+0.5" and rebuildTile (process_full_tiles.py:340, 363-414) for one tile.
+ *   pred_dev    [n, S, S]  generator outputs (last channel), in generation order
+ *   key_dev     [n, 2]     int32 (x, y) of each patch relative to the tile origin (padded coords)
+ *   dmm_dev     [n, 2]     float32 (dem_min, dem_max) of each patch
+ *   mean/std    [T, T] float32, good [T, T] uint8
+ * as_implemented != 0 reproduces the reference's aliased variance update. */
+int msr_stitch_tile(msr_handle* h, const float* pred_dev, const int32_t* key_dev, const float* dmm_dev, int32_t n,
+                    int32_t tile_size, int32_t stride, float no_value, int32_t as_implemented,
+                    float* mean_dev, float* std_dev, uint8_t* good_dev, void* stream);
+
+/* Optional: replace the library's own blending window (makeGaussianKernel + 1e-7, purged S//16 per side,
+ * process_full_tiles.py:347-361,391-393) by a caller-computed float64 [S-2p, S-2p] HOST array — the Python
+ * host passes NumPy's own evaluation so the GPU stitcher is bit-identical to the NumPy reference. */
+int msr_set_blend_window(msr_handle* h, const double* host_window, int32_t side);
+
+/* ---- measurement ----------------------------------------------------------------------------- */
+typedef struct {
+    char name[48];        /* kernel family, e.g. "conv_igemm_f32" */
+    int64_t launches;
+    double device_ms;     /* sum of hipEvent-bracketed launch durations on the call's stream */
+    double flops;         /* algorithmic FLOPs of those launches (2*MACs), 0 for memory-bound families */
+    double bytes;         /* algorithmic bytes of those launches */
+} msr_kernel_stat;
+/* When on, every kernel launch of msr_forward is bracketed by hipEvents on the call's stream. */
+int msr_profile_enable(msr_handle* h, int32_t on);
+int msr_profile_reset(msr_handle* h);
+/* Synchronises the recorded events and fills up to cap entries; *n = number of families. */
+int msr_profile_read(msr_handle* h, msr_kernel_stat* out, int32_t cap, int32_t* n);
+/* Algorithmic FLOPs of one msr_forward call (all patches), the figure BASELINE.md section 2 derives. */
+int msr_forward_flops(const msr_handle* h, double* flops);
+/* Debug / per-block parity aid: copy a named workspace tensor of the last msr_forward to a HOST buffer
+ * (names: "ws.gen.x0", "ws.gen.rb3.x1", "ws.gen.rb3.out", "ws.enc.mv", ...).  Synchronises the device. */
+int msr_debug_tensor(msr_handle* h, const char* name, float* host_out, int64_t count);
+/* Bytes of device memory held by the handle (weights + workspace). */
+int msr_device_bytes(const msr_handle* h, int64_t* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOONSR_H */

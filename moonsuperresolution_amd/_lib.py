@@ -1,0 +1,100 @@
+"""ctypes binding of libmoonsr_hip.so (include/moonsr.h).  No CPU fallback: a missing library is an error."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libmoonsr_hip.so")
+
+MSR_OK = 0
+MSR_ERR_INVALID = -1
+MSR_ERR_DEVICE = -2
+MSR_ERR_STATE = -3
+MSR_ERR_NOMEM = -4
+
+VARIANT_IDS = {"gaugan": 0, "gaugan_no_kl": 1, "cnn": 2, "pix2pix": 3}
+
+
+class MsrConfig(C.Structure):
+    _fields_ = [("image_size", C.c_int32), ("batch_size", C.c_int32), ("latent_dim", C.c_int32),
+                ("variant", C.c_int32), ("device", C.c_int32), ("flags", C.c_int32)]
+
+
+class MsrKernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("device_ms", C.c_double),
+                ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+# every symbol include/moonsr.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = [
+    ("msr_abi_version", C.c_int, []),
+    ("msr_create", C.c_int, [C.POINTER(MsrConfig), C.POINTER(_P)]),
+    ("msr_destroy", C.c_int, [_P]),
+    ("msr_last_error", C.c_char_p, [_P]),
+    ("msr_load_weight", C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int32]),
+    ("msr_weight_count", C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("msr_weight_name", C.c_char_p, [_P, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    ("msr_forward", C.c_int, [_P, _P, _P, _P, C.c_int32, _P]),
+    ("msr_last_latent", C.c_int, [_P, _P, _P]),
+    ("msr_patch_stats", C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_float, _P, _P, _P]),
+    ("msr_extract_patches", C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P, _P]),
+    ("msr_stitch_tile", C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, _P, _P, _P]),
+    ("msr_set_blend_window", C.c_int, [_P, _P, C.c_int32]),
+    ("msr_profile_enable", C.c_int, [_P, C.c_int32]),
+    ("msr_profile_reset", C.c_int, [_P]),
+    ("msr_profile_read", C.c_int, [_P, C.POINTER(MsrKernelStat), C.c_int32, C.POINTER(C.c_int32)]),
+    ("msr_forward_flops", C.c_int, [_P, C.POINTER(C.c_double)]),
+    ("msr_debug_tensor", C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
+    ("msr_device_bytes", C.c_int, [_P, C.POINTER(C.c_int64)]),
+]
+
+_lib: Optional[C.CDLL] = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libmoonsr_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    res = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if verbose or res.returncode:
+        print(res.stdout[-4000:])
+        print(res.stderr[-4000:])
+    if res.returncode:
+        raise RuntimeError("building libmoonsr_hip.so failed (see output above)")
+    return LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raise (never fall back) if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C moonsuperresolution_amd/csrc`).  moonsuperresolution_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)   # AttributeError if the ABI lost a symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.msr_abi_version() != 1:
+        raise RuntimeError("libmoonsr_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def raise_for(lib: C.CDLL, handle, rc: int, what: str) -> None:
+    """Map msr_status to the reference's exception style (ValueError / RuntimeError)."""
+    if rc == MSR_OK:
+        return
+    msg = lib.msr_last_error(handle)
+    text = f"{what}: {msg.decode() if msg else 'error'} (msr_status {rc})"
+    if rc == MSR_ERR_INVALID:
+        raise ValueError(text)
+    if rc == MSR_ERR_NOMEM:
+        raise MemoryError(text)
+    raise RuntimeError(text)

@@ -1,0 +1,957 @@
+// api.hip — the C ABI of libmoonsr_hip.so (include/moonsr.h): handle, weight re-layout, workspace planning
+// and the per-call launch plan of the generator(call).  Host logic only; kernels live in the other files.
+#include "../../include/moonsr.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+using namespace msr;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct WeightSpec {
+    std::string name;
+    std::vector<int64_t> shape;
+    bool loaded = false;
+};
+
+enum OpType { OP_CONV, OP_SMALLCIN, OP_MOMENTS, OP_NORMACT, OP_DENSE, OP_LATENT, OP_HEAD, OP_DIRECT };
+enum Family { FAM_CONV = 0, FAM_SMALLCIN, FAM_MOMENTS, FAM_NORMACT, FAM_DENSE, FAM_LATENT, FAM_HEAD, FAM_DIRECT,
+              FAM_COUNT };
+const char* kFamilyName[FAM_COUNT] = {"conv_igemm_f32", "conv_smallcin", "moments", "norm_act", "dense",
+                                      "latent", "head_up_conv4x4", "conv_direct"};
+
+struct Op {
+    OpType type;
+    double flops = 0, bytes = 0;
+    // flags for per-call pointers
+    bool src_is_input = false, out_is_output = false, eps_is_input = false;
+    ConvParams conv{}; int epi = 0, tile = 0;
+    SmallCinParams sc{};
+    struct { const float* x; int G, P, C; float eps; float* mean; float* stdv; } mom{};
+    NormActParams na{};
+    struct { const float* x; const float* W; const float* bias; float* y; int B, K, N; } dense{};
+    struct { const float* mv; float* z; int B, L, sampler; } lat{};
+    struct { const float* x; const float* weff; float bias; int B, r, C; float slope; int tanh_out; } head{};
+    DirectConvParams dc{};
+};
+
+struct ProfRec { int fam; hipEvent_t a, b; double flops, bytes; };
+
+}  // namespace
+
+struct msr_handle {
+    msr_config cfg{};
+    int S = 0, B = 0, L = 0, variant = 0;
+    std::string err;
+    std::vector<WeightSpec> specs;
+    std::map<std::string, int> spec_index;
+    std::map<std::string, float*> dev;          // device tensors: weights (re-laid-out) and workspace
+    std::map<std::string, size_t> dev_bytes;
+    std::map<std::string, std::vector<float>> host_small;   // small host copies needed at plan time (BN, head)
+    size_t total_bytes = 0;
+    bool planned = false;
+    std::vector<Op> ops;
+    double fwd_flops = 0;
+    double* mom_partial = nullptr;
+    float* dense_partial = nullptr;
+    float* z = nullptr;
+    // tiler
+    double* window = nullptr;     // [S-2p, S-2p] float64
+    int* stitch_grid = nullptr;
+    int stitch_grid_cap = 0;
+    // profiling
+    bool prof_on = false;
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+};
+
+namespace {
+
+int fail(msr_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                                     \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return fail(h, MSR_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                        __LINE__);                                                                          \
+    } while (0)
+
+const int kGenFilters[6] = {1024, 1024, 1024, 512, 256, 128};
+const int kEncChannels[5] = {64, 128, 256, 512, 512};
+const int kP2PDown[8] = {64, 128, 256, 512, 512, 512, 512, 512};
+const int kP2PUp[7] = {512, 512, 512, 512, 256, 128, 64};
+
+void add_spec(msr_handle* h, const std::string& name, std::vector<int64_t> shape) {
+    h->spec_index[name] = (int)h->specs.size();
+    h->specs.push_back({name, std::move(shape), false});
+}
+
+void build_specs(msr_handle* h) {
+    char n[128];
+    if (h->variant == MSR_PIX2PIX) {
+        int cin = 2;
+        for (int i = 1; i <= 8; ++i) {
+            const int c = kP2PDown[i - 1];
+            snprintf(n, sizeof n, "p2p.down%d.kernel", i); add_spec(h, n, {4, 4, cin, c});
+            if (i > 1)
+                for (const char* q : {"gamma", "beta", "moving_mean", "moving_variance"}) {
+                    snprintf(n, sizeof n, "p2p.down%d.bn.%s", i, q); add_spec(h, n, {c});
+                }
+            cin = c;
+        }
+        for (int i = 1; i <= 7; ++i) {
+            const int c = kP2PUp[i - 1];
+            snprintf(n, sizeof n, "p2p.up%d.kernel", i); add_spec(h, n, {4, 4, c, cin});
+            for (const char* q : {"gamma", "beta", "moving_mean", "moving_variance"}) {
+                snprintf(n, sizeof n, "p2p.up%d.bn.%s", i, q); add_spec(h, n, {c});
+            }
+            cin = c + kP2PDown[6 - (i - 1)];
+        }
+        add_spec(h, "p2p.last.kernel", {4, 4, 1, cin});
+        add_spec(h, "p2p.last.bias", {1});
+        return;
+    }
+    const int S = h->S, L = h->L;
+    int cin = 2;
+    for (int i = 1; i <= 5; ++i) {
+        const int c = kEncChannels[i - 1];
+        snprintf(n, sizeof n, "enc.ds%d.kernel", i); add_spec(h, n, {3, 3, cin, c});
+        if (i > 1) {
+            snprintf(n, sizeof n, "enc.ds%d.in.gamma", i); add_spec(h, n, {c});
+            snprintf(n, sizeof n, "enc.ds%d.in.beta", i); add_spec(h, n, {c});
+        }
+        cin = c;
+    }
+    const int64_t flat = (int64_t)(S / 32) * (S / 32) * 512;
+    for (const char* q : {"mean", "variance"}) {
+        snprintf(n, sizeof n, "enc.%s.kernel", q); add_spec(h, n, {flat, L});
+        snprintf(n, sizeof n, "enc.%s.bias", q); add_spec(h, n, {L});
+    }
+    const int sw = S / 64;
+    add_spec(h, "gen.dense.kernel", {L, (int64_t)sw * sw * 1024});
+    add_spec(h, "gen.dense.bias", {(int64_t)sw * sw * 1024});
+    cin = 1024;
+    for (int i = 1; i <= 6; ++i) {
+        const int f = kGenFilters[i - 1];
+        const bool learned = f != cin;
+        for (int j = 1; j <= (learned ? 3 : 2); ++j) {
+            const int c = j == 2 ? f : cin;
+            snprintf(n, sizeof n, "gen.rb%d.spade_%d.conv.kernel", i, j); add_spec(h, n, {3, 3, 2, 128});
+            snprintf(n, sizeof n, "gen.rb%d.spade_%d.conv.bias", i, j); add_spec(h, n, {128});
+            snprintf(n, sizeof n, "gen.rb%d.spade_%d.conv_gamma.kernel", i, j); add_spec(h, n, {3, 3, 128, c});
+            snprintf(n, sizeof n, "gen.rb%d.spade_%d.conv_gamma.bias", i, j); add_spec(h, n, {c});
+            snprintf(n, sizeof n, "gen.rb%d.spade_%d.conv_beta.kernel", i, j); add_spec(h, n, {3, 3, 128, c});
+            snprintf(n, sizeof n, "gen.rb%d.spade_%d.conv_beta.bias", i, j); add_spec(h, n, {c});
+        }
+        for (int j = 1; j <= (learned ? 3 : 2); ++j) {
+            const int ci = j == 2 ? f : cin;
+            snprintf(n, sizeof n, "gen.rb%d.conv_%d.kernel", i, j); add_spec(h, n, {3, 3, ci, f});
+            snprintf(n, sizeof n, "gen.rb%d.conv_%d.bias", i, j); add_spec(h, n, {f});
+        }
+        cin = f;
+    }
+    add_spec(h, "gen.head.kernel", {4, 4, 128, 1});
+    add_spec(h, "gen.head.bias", {1});
+}
+
+int dev_alloc(msr_handle* h, const std::string& key, size_t floats, bool zero, float** out) {
+    auto it = h->dev.find(key);
+    if (it != h->dev.end()) {
+        if (h->dev_bytes[key] != floats * sizeof(float))
+            return fail(h, MSR_ERR_STATE, "buffer %s re-allocated with a different size", key.c_str());
+        *out = it->second;
+        return MSR_OK;
+    }
+    float* p = nullptr;
+    hipError_t e = hipMalloc(&p, std::max<size_t>(floats, 4) * sizeof(float));
+    if (e != hipSuccess)
+        return fail(h, MSR_ERR_NOMEM, "hipMalloc of %zu bytes for %s failed: %s", floats * sizeof(float), key.c_str(),
+                    hipGetErrorString(e));
+    if (zero) {
+        e = hipMemset(p, 0, std::max<size_t>(floats, 4) * sizeof(float));
+        if (e != hipSuccess) return fail(h, MSR_ERR_DEVICE, "hipMemset for %s failed", key.c_str());
+    }
+    h->dev[key] = p;
+    h->dev_bytes[key] = floats * sizeof(float);
+    h->total_bytes += floats * sizeof(float);
+    *out = p;
+    return MSR_OK;
+}
+
+int upload(msr_handle* h, const std::string& key, const float* host, size_t floats) {
+    float* d = nullptr;
+    int rc = dev_alloc(h, key, floats, false, &d);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpy(d, host, floats * sizeof(float), hipMemcpyHostToDevice));
+    return MSR_OK;
+}
+
+float* D(msr_handle* h, const std::string& key) {
+    auto it = h->dev.find(key);
+    return it == h->dev.end() ? nullptr : it->second;
+}
+
+// HWIO [kh,kw,Cin,Cout] -> [tap][Cout][Cin]  (K contiguous per output channel, the igemm B-operand layout)
+void hwio_to_tap_oc_ic(const float* src, float* dst, int taps, int cin, int cout, int dst_rows, const int* rowmap) {
+    for (int t = 0; t < taps; ++t)
+        for (int ci = 0; ci < cin; ++ci) {
+            const float* s = src + ((size_t)t * cin + ci) * cout;
+            for (int co = 0; co < cout; ++co) {
+                const int row = rowmap ? rowmap[co] : co;
+                dst[((size_t)t * dst_rows + row) * cin + ci] = s[co];
+            }
+        }
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int msr_abi_version(void) { return MSR_ABI_VERSION; }
+
+const char* msr_last_error(const msr_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int msr_create(const msr_config* cfg, msr_handle** out) {
+    if (!cfg || !out) return fail(nullptr, MSR_ERR_INVALID, "msr_create: null argument");
+    *out = nullptr;
+    const int S = cfg->image_size, B = cfg->batch_size;
+    if (cfg->variant < MSR_GAUGAN || cfg->variant > MSR_PIX2PIX)
+        return fail(nullptr, MSR_ERR_INVALID, "unknown variant %d", cfg->variant);
+    if (cfg->variant == MSR_PIX2PIX) {
+        if (S != 256) return fail(nullptr, MSR_ERR_INVALID, "pix2pix input is fixed to 256x256 (pix2pix.py:7), got %d", S);
+    } else {
+        if (S < 64 || (S & (S - 1)))
+            return fail(nullptr, MSR_ERR_INVALID, "image_size must be a power of two >= 64, got %d", S);
+        if (cfg->latent_dim <= 0 || cfg->latent_dim % 4)
+            return fail(nullptr, MSR_ERR_INVALID, "latent_dim must be a positive multiple of 4, got %d", cfg->latent_dim);
+    }
+    if (B < 1 || B > 16) return fail(nullptr, MSR_ERR_INVALID, "batch_size must be in [1,16], got %d", B);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, MSR_ERR_DEVICE, "no HIP device visible: libmoonsr_hip has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, MSR_ERR_DEVICE, "device %d out of range (%d visible)", cfg->device, ndev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess)
+        return fail(nullptr, MSR_ERR_DEVICE, "hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, MSR_ERR_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only",
+                    cfg->device, prop.gcnArchName);
+    if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, MSR_ERR_DEVICE, "hipSetDevice failed");
+    if (conv_igemm_init() != hipSuccess)
+        return fail(nullptr, MSR_ERR_DEVICE, "could not set the dynamic-LDS attribute of the conv kernels");
+    auto h = std::make_unique<msr_handle>();
+    h->cfg = *cfg;
+    h->S = S; h->B = B; h->L = cfg->latent_dim; h->variant = cfg->variant;
+    build_specs(h.get());
+    *out = h.release();
+    return MSR_OK;
+}
+
+int msr_destroy(msr_handle* h) {
+    if (!h) return MSR_OK;
+    hipSetDevice(h->cfg.device);
+    hipDeviceSynchronize();
+    for (auto& kv : h->dev) hipFree(kv.second);
+    if (h->mom_partial) hipFree(h->mom_partial);
+    if (h->dense_partial) hipFree(h->dense_partial);
+    if (h->window) hipFree(h->window);
+    if (h->stitch_grid) hipFree(h->stitch_grid);
+    for (auto e : h->ev_pool) hipEventDestroy(e);
+    delete h;
+    return MSR_OK;
+}
+
+int msr_weight_count(const msr_handle* h, int32_t* expected, int32_t* loaded) {
+    if (!h) return MSR_ERR_INVALID;
+    int l = 0;
+    for (auto& s : h->specs) l += s.loaded;
+    if (expected) *expected = (int32_t)h->specs.size();
+    if (loaded) *loaded = l;
+    return MSR_OK;
+}
+
+const char* msr_weight_name(const msr_handle* h, int32_t i, int64_t* shape4, int32_t* rank) {
+    if (!h || i < 0 || i >= (int)h->specs.size()) return nullptr;
+    const auto& s = h->specs[i];
+    if (rank) *rank = (int32_t)s.shape.size();
+    if (shape4)
+        for (size_t k = 0; k < s.shape.size() && k < 4; ++k) shape4[k] = s.shape[k];
+    return s.name.c_str();
+}
+
+static bool ends_with(const std::string& s, const char* suf) {
+    const size_t n = std::strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+int msr_load_weight(msr_handle* h, const char* name_c, const float* host, const int64_t* shape, int32_t rank) {
+    if (!h) return MSR_ERR_INVALID;
+    if (!name_c || !host || !shape) return fail(h, MSR_ERR_INVALID, "msr_load_weight: null argument");
+    const std::string name = name_c;
+    auto it = h->spec_index.find(name);
+    if (it == h->spec_index.end()) return fail(h, MSR_ERR_INVALID, "unexpected weight name '%s'", name_c);
+    WeightSpec& sp = h->specs[it->second];
+    if (rank != (int)sp.shape.size()) return fail(h, MSR_ERR_INVALID, "%s: rank %d, expected %zu", name_c, rank, sp.shape.size());
+    size_t count = 1;
+    for (int k = 0; k < rank; ++k) {
+        if (shape[k] != sp.shape[k])
+            return fail(h, MSR_ERR_INVALID, "%s: dim %d is %lld, expected %lld", name_c, k, (long long)shape[k],
+                        (long long)sp.shape[k]);
+        count *= (size_t)shape[k];
+    }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    h->planned = false;
+    int rc = MSR_OK;
+    const auto& s = sp.shape;
+    if (name.rfind("p2p.", 0) == 0) {
+        if (ends_with(name, ".kernel") && name.find(".down") == std::string::npos) {
+            // Conv2DTranspose [kh,kw,Cout,Cin] -> HWIO [kh,kw,Cin,Cout]
+            const int taps = 16, co = (int)s[2], ci = (int)s[3];
+            std::vector<float> t(count);
+            for (int tp = 0; tp < taps; ++tp)
+                for (int o = 0; o < co; ++o)
+                    for (int i = 0; i < ci; ++i) t[((size_t)tp * ci + i) * co + o] = host[((size_t)tp * co + o) * ci + i];
+            rc = upload(h, name, t.data(), count);
+        } else if (ends_with(name, ".kernel")) {
+            rc = upload(h, name, host, count);
+        } else {
+            h->host_small[name].assign(host, host + count);   // BN statistics / bias: folded at plan time
+        }
+    } else if (name == "enc.ds1.kernel" || ends_with(name, ".conv.kernel") || ends_with(name, ".conv.bias") ||
+               ends_with(name, ".in.gamma") || ends_with(name, ".in.beta") || name == "gen.dense.kernel" ||
+               name == "gen.dense.bias" || (name.find(".conv_") != std::string::npos && ends_with(name, ".bias") &&
+                                            name.find("spade") == std::string::npos)) {
+        rc = upload(h, name, host, count);   // used in the reference layout
+    } else if (name == "enc.mean.kernel" || name == "enc.variance.kernel") {
+        // concatenate the two heads into one [K, 2L] matrix so the flatten is streamed once
+        float* d = nullptr;
+        rc = dev_alloc(h, "enc.heads.kernel", (size_t)s[0] * 2 * h->L, false, &d);
+        if (!rc) {
+            const size_t coff = name == "enc.mean.kernel" ? 0 : (size_t)h->L;
+            HIPCHK(h, hipMemcpy2D(d + coff, (size_t)2 * h->L * sizeof(float), host, (size_t)h->L * sizeof(float),
+                                  (size_t)h->L * sizeof(float), (size_t)s[0], hipMemcpyHostToDevice));
+        }
+    } else if (name == "enc.mean.bias" || name == "enc.variance.bias") {
+        float* d = nullptr;
+        rc = dev_alloc(h, "enc.heads.bias", (size_t)2 * h->L, false, &d);
+        if (!rc) HIPCHK(h, hipMemcpy(d + (name == "enc.mean.bias" ? 0 : h->L), host, h->L * sizeof(float), hipMemcpyHostToDevice));
+    } else if (name == "gen.head.kernel") {
+        // effective per-parity taps of Conv2D(1,4,'same') applied to a nearest-2x up-sampled tensor
+        const int C = (int)s[2];
+        std::vector<float> weff((size_t)36 * C, 0.f);
+        auto dmap = [](int parity, int k) { return parity == 0 ? (k == 0 ? 0 : k == 3 ? 2 : 1) : (k < 2 ? 1 : 2); };
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px)
+                for (int kh = 0; kh < 4; ++kh)
+                    for (int kw = 0; kw < 4; ++kw) {
+                        const int dy = dmap(py, kh), dx = dmap(px, kw);
+                        float* dst = &weff[((((size_t)py * 2 + px) * 3 + dy) * 3 + dx) * C];
+                        const float* src = host + ((size_t)kh * 4 + kw) * C;
+                        for (int c = 0; c < C; ++c) dst[c] += src[c];
+                    }
+        rc = upload(h, "gen.head.weff", weff.data(), weff.size());
+    } else if (name == "gen.head.bias") {
+        h->host_small[name].assign(host, host + count);
+    } else if (ends_with(name, ".conv_gamma.kernel") || ends_with(name, ".conv_beta.kernel")) {
+        // gamma and beta convs share their input: ONE GEMM with N = 2C whose columns interleave
+        // (32 gamma channels | 32 beta channels) so a wave holds both for the same pixel and channel.
+        const bool is_beta = ends_with(name, ".conv_beta.kernel");
+        const int cin = (int)s[2], C = (int)s[3];
+        const std::string base = name.substr(0, name.rfind(".conv_"));
+        float* d = nullptr;
+        rc = dev_alloc(h, base + ".gb.kernel", (size_t)9 * 2 * C * cin, false, &d);
+        if (!rc) {
+            std::vector<int> rowmap(C);
+            for (int c = 0; c < C; ++c) rowmap[c] = (c / 32) * 64 + (is_beta ? 32 : 0) + (c % 32);
+            // stage through a host image of the combined tensor; the other half is filled by the sibling call
+            std::vector<float>& img = h->host_small[base + ".gb.kernel"];
+            img.resize((size_t)9 * 2 * C * cin);
+            hwio_to_tap_oc_ic(host, img.data(), 9, cin, C, 2 * C, rowmap.data());
+            HIPCHK(h, hipMemcpy(d, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+    } else if (ends_with(name, ".conv_gamma.bias") || ends_with(name, ".conv_beta.bias")) {
+        const bool is_beta = ends_with(name, ".conv_beta.bias");
+        const int C = (int)s[0];
+        const std::string base = name.substr(0, name.rfind(".conv_"));
+        std::vector<float>& img = h->host_small[base + ".gb.bias"];
+        img.resize((size_t)2 * C);
+        for (int c = 0; c < C; ++c) img[(c / 32) * 64 + (is_beta ? 32 : 0) + (c % 32)] = host[c];
+        rc = upload(h, base + ".gb.bias", img.data(), img.size());
+    } else if (ends_with(name, ".kernel")) {
+        // encoder ds2..5 and ResidualBlock conv_1/2/3: HWIO -> [tap][Cout][Cin]
+        const int taps = (int)(s[0] * s[1]), cin = (int)s[2], cout = (int)s[3];
+        std::vector<float> t(count);
+        hwio_to_tap_oc_ic(host, t.data(), taps, cin, cout, cout, nullptr);
+        rc = upload(h, name, t.data(), count);
+    } else {
+        rc = upload(h, name, host, count);
+    }
+    if (rc) return rc;
+    sp.loaded = true;
+    return MSR_OK;
+}
+
+}  // extern "C"
+
+// ================================================================================================
+// plan
+// ================================================================================================
+namespace {
+
+struct Padded {   // zero-bordered NHWC activation [B, r+2, r+2, C]
+    float* base = nullptr;
+    int r = 0, C = 0;
+    int py() const { return (r + 2) * C; }
+    int pb() const { return (r + 2) * (r + 2) * C; }
+    int interior() const { return py() + C; }
+};
+
+int alloc_padded(msr_handle* h, const std::string& key, int r, int C, Padded* out) {
+    out->r = r; out->C = C;
+    return dev_alloc(h, key, (size_t)h->B * (r + 2) * (r + 2) * C, true, &out->base);
+}
+
+Op conv_op(const Padded& in, const float* wt, const float* bias, int B, int rout, int N, int stride, int epi) {
+    Op op; op.type = OP_CONV; op.epi = epi;
+    ConvParams& c = op.conv;
+    c.in = stride == 1 ? in.base : in.base + in.interior();
+    c.wt = wt; c.bias = bias;
+    c.B = B; c.Hout = rout; c.Wout = rout; c.Cin = in.C; c.N = N;
+    c.KH = 3; c.KW = 3; c.stride = stride;
+    c.in_py = in.py(); c.in_pb = in.pb();
+    c.slope = 0.2f;
+    op.tile = conv_pick_tile(B * rout * rout, N);
+    op.flops = 2.0 * B * rout * rout * (double)in.C * N * 9;
+    return op;
+}
+
+void out_dense(ConvParams& c, float* out, int r, int C) {
+    c.out = out; c.out_px = C; c.out_py = r * C; c.out_pb = r * r * C; c.out_off = 0;
+}
+void out_padded(ConvParams& c, const Padded& p) {
+    c.out = p.base; c.out_px = p.C; c.out_py = p.py(); c.out_pb = p.pb(); c.out_off = p.interior();
+}
+void aux_dense(ConvParams& c, const float* x, int rx, int C, int shift) {
+    c.aux = x; c.aux_px = C; c.aux_py = rx * C; c.aux_pb = rx * rx * C; c.aux_shift = shift;
+}
+
+Op moments_op(const float* x, int G, int P, int C, float eps, float* mean, float* stdv) {
+    Op op; op.type = OP_MOMENTS;
+    op.mom = {x, G, P, C, eps, mean, stdv};
+    op.bytes = (double)G * P * C * 4;
+    return op;
+}
+
+int plan_spade(msr_handle* h) {
+    const int S = h->S, B = h->B, L = h->L;
+    char n[160];
+    int rc;
+    auto need = [&](const std::string& k) -> float* { return D(h, k); };
+    size_t mom_doubles = 0;
+    auto mom_need = [&](int G, int P, int C) { mom_doubles = std::max(mom_doubles, (size_t)G * moments_chunks(P) * C * 2); };
+
+    // ---------------- encoder (networks.py:8-34) ----------------
+    Padded e_in;   // input of the next strided conv
+    rc = alloc_padded(h, "ws.enc.p1", S / 2, 64, &e_in); if (rc) return rc;
+    {
+        Op op; op.type = OP_SMALLCIN; op.src_is_input = true;
+        SmallCinParams& p = op.sc;
+        p.w = need("enc.ds1.kernel"); p.bias = nullptr; p.out = e_in.base;
+        p.B = B; p.S = S; p.Hout = S / 2; p.Cout = 64;
+        p.ay = 2; p.cy = 0; p.lim = S; p.f = 1; p.o = 0;
+        p.out_px = 64; p.out_py = e_in.py(); p.out_pb = e_in.pb(); p.out_off = e_in.interior();
+        p.act = 2; p.slope = 0.2f;
+        op.flops = 2.0 * B * (S / 2) * (S / 2) * 18.0 * 64;
+        h->ops.push_back(op);
+    }
+    float* flat = nullptr;
+    const int rlast = S / 32;
+    for (int i = 2; i <= 5; ++i) {
+        const int c = kEncChannels[i - 1], r = S >> i;
+        float* raw; float *mean, *stdv;
+        snprintf(n, sizeof n, "ws.enc.raw%d", i); rc = dev_alloc(h, n, (size_t)B * r * r * c, false, &raw); if (rc) return rc;
+        snprintf(n, sizeof n, "ws.enc.mean%d", i); rc = dev_alloc(h, n, (size_t)B * c, false, &mean); if (rc) return rc;
+        snprintf(n, sizeof n, "ws.enc.std%d", i); rc = dev_alloc(h, n, (size_t)B * c, false, &stdv); if (rc) return rc;
+        float* zero_bias; rc = dev_alloc(h, "ws.zero_bias", 2048, true, &zero_bias); if (rc) return rc;
+        snprintf(n, sizeof n, "enc.ds%d.kernel", i);
+        Op cv = conv_op(e_in, need(n), zero_bias, B, r, c, 2, EPI_BIAS);
+        out_dense(cv.conv, raw, r, c);
+        h->ops.push_back(cv);
+        h->ops.push_back(moments_op(raw, B, r * r, c, 1e-3f, mean, stdv));
+        mom_need(B, r * r, c);
+        Op na; na.type = OP_NORMACT;
+        snprintf(n, sizeof n, "enc.ds%d.in.gamma", i); na.na.gamma = need(n);
+        snprintf(n, sizeof n, "enc.ds%d.in.beta", i); na.na.beta = need(n);
+        na.na.x = raw; na.na.mean = mean; na.na.stdv = stdv;
+        na.na.B = B; na.na.H = r; na.na.W = r; na.na.C = c; na.na.slope = 0.2f;
+        if (i < 5) {
+            Padded nx;
+            snprintf(n, sizeof n, "ws.enc.p%d", i); rc = alloc_padded(h, n, r, c, &nx); if (rc) return rc;
+            na.na.out = nx.base; na.na.out_px = c; na.na.out_py = nx.py(); na.na.out_pb = nx.pb(); na.na.out_off = nx.interior();
+            e_in = nx;
+        } else {
+            rc = dev_alloc(h, "ws.enc.flat", (size_t)B * r * r * c, false, &flat); if (rc) return rc;
+            na.na.out = flat; na.na.out_px = c; na.na.out_py = r * c; na.na.out_pb = r * r * c; na.na.out_off = 0;
+        }
+        na.bytes = 2.0 * B * r * r * c * 4;
+        h->ops.push_back(na);
+    }
+    // Dense mean | variance (networks.py:32-33), then the sampler (sampling.py:16) or mean+variance (model.py:267)
+    const int K = rlast * rlast * 512;
+    float* mv; rc = dev_alloc(h, "ws.enc.mv", (size_t)B * 2 * L, false, &mv); if (rc) return rc;
+    rc = dev_alloc(h, "ws.z", (size_t)B * L, false, &h->z); if (rc) return rc;
+    size_t dense_part = (size_t)dense_splits(K) * B * 2 * L;
+    {
+        Op op; op.type = OP_DENSE;
+        op.dense = {flat, need("enc.heads.kernel"), need("enc.heads.bias"), mv, B, K, 2 * L};
+        op.flops = 2.0 * B * K * 2.0 * L; op.bytes = (double)K * 2 * L * 4;
+        h->ops.push_back(op);
+        Op lt; lt.type = OP_LATENT; lt.eps_is_input = true;
+        lt.lat = {mv, h->z, B, L, h->variant == MSR_GAUGAN ? 1 : 0};
+        h->ops.push_back(lt);
+    }
+    // ---------------- generator (networks.py:37-57) ----------------
+    const int sw = S / 64;
+    const int N0 = sw * sw * 1024;
+    float* x_prev; rc = dev_alloc(h, "ws.gen.x0", (size_t)B * N0, false, &x_prev); if (rc) return rc;
+    dense_part = std::max(dense_part, (size_t)dense_splits(L) * B * N0);
+    {
+        Op op; op.type = OP_DENSE;
+        op.dense = {h->z, need("gen.dense.kernel"), need("gen.dense.bias"), x_prev, B, L, N0};
+        op.flops = 2.0 * B * L * (double)N0; op.bytes = (double)L * N0 * 4;
+        h->ops.push_back(op);
+    }
+    float *st_mean, *st_std;   // batch moments of the block input
+    rc = dev_alloc(h, "ws.gen.mean_in0", 1024, false, &st_mean); if (rc) return rc;
+    rc = dev_alloc(h, "ws.gen.std_in0", 1024, false, &st_std); if (rc) return rc;
+    h->ops.push_back(moments_op(x_prev, 1, B * sw * sw, 1024, 1e-5f, st_mean, st_std));
+    mom_need(1, B * sw * sw, 1024);
+
+    int cin = 1024, r_prev = sw;
+    for (int i = 1; i <= 6; ++i) {
+        const int f = kGenFilters[i - 1];
+        const int r = sw << (i - 1);
+        const int shift = i > 1 ? 1 : 0;   // block input = UpSampling2D(previous output), folded into the index
+        const bool learned = f != cin;
+        float *x1, *skip = nullptr, *outb, *m1, *s1, *mo, *so;
+        snprintf(n, sizeof n, "ws.gen.rb%d.x1", i); rc = dev_alloc(h, n, (size_t)B * r * r * f, false, &x1); if (rc) return rc;
+        snprintf(n, sizeof n, "ws.gen.rb%d.out", i); rc = dev_alloc(h, n, (size_t)B * r * r * f, false, &outb); if (rc) return rc;
+        snprintf(n, sizeof n, "ws.gen.rb%d.mean1", i); rc = dev_alloc(h, n, f, false, &m1); if (rc) return rc;
+        snprintf(n, sizeof n, "ws.gen.rb%d.std1", i); rc = dev_alloc(h, n, f, false, &s1); if (rc) return rc;
+        snprintf(n, sizeof n, "ws.gen.rb%d.meano", i); rc = dev_alloc(h, n, f, false, &mo); if (rc) return rc;
+        snprintf(n, sizeof n, "ws.gen.rb%d.stdo", i); rc = dev_alloc(h, n, f, false, &so); if (rc) return rc;
+        if (learned) { snprintf(n, sizeof n, "ws.gen.rb%d.skip", i); rc = dev_alloc(h, n, (size_t)B * r * r * f, false, &skip); if (rc) return rc; }
+
+        // one SPADE layer + its consumer conv:  a = lrelu(SPADE(x)) ; y = conv(a)
+        auto spade_then_conv = [&](int j, const float* x, int rx, int xshift, int C, const float* mean,
+                                   const float* stdv, int conv_idx, float* y, int epi, const float* res, int res_r,
+                                   int res_shift) -> int {
+            char k[160];
+            Padded hb, ab;
+            snprintf(k, sizeof k, "ws.gen.rb%d.h%d", i, j); int rc2 = alloc_padded(h, k, r, 128, &hb); if (rc2) return rc2;
+            snprintf(k, sizeof k, "ws.gen.rb%d.a%d", i, j); rc2 = alloc_padded(h, k, r, C, &ab); if (rc2) return rc2;
+            Op em; em.type = OP_SMALLCIN; em.src_is_input = true;
+            SmallCinParams& p = em.sc;
+            snprintf(k, sizeof k, "gen.rb%d.spade_%d.conv.kernel", i, j); p.w = need(k);
+            snprintf(k, sizeof k, "gen.rb%d.spade_%d.conv.bias", i, j); p.bias = need(k);
+            p.out = hb.base; p.B = B; p.S = S; p.Hout = r; p.Cout = 128;
+            p.ay = 1; p.cy = -1; p.lim = r; p.f = S / r; p.o = (S / r) / 2;
+            p.out_px = 128; p.out_py = hb.py(); p.out_pb = hb.pb(); p.out_off = hb.interior();
+            p.act = 1; p.slope = 0.f;
+            em.flops = 2.0 * B * r * r * 18.0 * 128;
+            h->ops.push_back(em);
+            snprintf(k, sizeof k, "gen.rb%d.spade_%d.gb.kernel", i, j); const float* gbw = need(k);
+            snprintf(k, sizeof k, "gen.rb%d.spade_%d.gb.bias", i, j); const float* gbb = need(k);
+            Op gb = conv_op(hb, gbw, gbb, B, r, 2 * C, 1, EPI_SPADE);
+            out_padded(gb.conv, ab);
+            aux_dense(gb.conv, x, rx, C, xshift);
+            gb.conv.mean = mean; gb.conv.stdv = stdv;
+            h->ops.push_back(gb);
+            snprintf(k, sizeof k, "gen.rb%d.conv_%d.kernel", i, conv_idx); const float* cw = need(k);
+            snprintf(k, sizeof k, "gen.rb%d.conv_%d.bias", i, conv_idx); const float* cb = need(k);
+            Op cv = conv_op(ab, cw, cb, B, r, f, 1, epi);
+            out_dense(cv.conv, y, r, f);
+            if (epi == EPI_RES) aux_dense(cv.conv, res, res_r, f, res_shift);
+            h->ops.push_back(cv);
+            return MSR_OK;
+        };
+        // x1 = conv_1(lrelu(spade_1(x)))                                   blocks.py:29-30
+        rc = spade_then_conv(1, x_prev, r_prev, shift, cin, st_mean, st_std, 1, x1, EPI_BIAS, nullptr, 0, 0); if (rc) return rc;
+        h->ops.push_back(moments_op(x1, 1, B * r * r, f, 1e-5f, m1, s1));
+        mom_need(1, B * r * r, f);
+        if (learned) {
+            // skip = conv_3(lrelu(spade_3(x)))                             blocks.py:33-34
+            rc = spade_then_conv(3, x_prev, r_prev, shift, cin, st_mean, st_std, 3, skip, EPI_BIAS, nullptr, 0, 0); if (rc) return rc;
+            // out = skip + conv_2(lrelu(spade_2(x1)))                      blocks.py:31-32,38
+            rc = spade_then_conv(2, x1, r, 0, f, m1, s1, 2, outb, EPI_RES, skip, r, 0); if (rc) return rc;
+        } else {
+            // out = x + conv_2(lrelu(spade_2(x1))), x read through the folded up-sample
+            rc = spade_then_conv(2, x1, r, 0, f, m1, s1, 2, outb, EPI_RES, x_prev, r_prev, shift); if (rc) return rc;
+        }
+        // moments of the block output == moments of its nearest-2x up-sample (every value is repeated 4x)
+        h->ops.push_back(moments_op(outb, 1, B * r * r, f, 1e-5f, mo, so));
+        mom_need(1, B * r * r, f);
+        x_prev = outb; r_prev = r; cin = f; st_mean = mo; st_std = so;
+    }
+    {
+        Op hd; hd.type = OP_HEAD; hd.out_is_output = true;
+        hd.head = {x_prev, need("gen.head.weff"), h->host_small["gen.head.bias"][0], B, r_prev, 128, 0.2f, 0};
+        hd.flops = 2.0 * B * S * S * 16.0 * 128;
+        h->ops.push_back(hd);
+    }
+    HIPCHK(h, hipMalloc(&h->mom_partial, std::max<size_t>(mom_doubles, 16) * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->dense_partial, std::max<size_t>(dense_part, 16) * sizeof(float)));
+    h->total_bytes += mom_doubles * sizeof(double) + dense_part * sizeof(float);
+    return MSR_OK;
+}
+
+int plan_pix2pix(msr_handle* h) {
+    const int B = h->B;
+    char n[128];
+    int rc;
+    auto fold_bn = [&](const std::string& prefix, int C, float** scale, float** shift) -> int {
+        const auto& g = h->host_small[prefix + ".gamma"];
+        const auto& b = h->host_small[prefix + ".beta"];
+        const auto& m = h->host_small[prefix + ".moving_mean"];
+        const auto& v = h->host_small[prefix + ".moving_variance"];
+        std::vector<float> sc(C), sh(C);
+        for (int c = 0; c < C; ++c) {
+            sc[c] = g[c] / std::sqrt(v[c] + 1e-3f);   // keras BatchNormalization epsilon
+            sh[c] = b[c] - m[c] * sc[c];
+        }
+        int r2 = upload(h, prefix + ".scale", sc.data(), C); if (r2) return r2;
+        r2 = upload(h, prefix + ".shift", sh.data(), C); if (r2) return r2;
+        *scale = D(h, prefix + ".scale"); *shift = D(h, prefix + ".shift");
+        return MSR_OK;
+    };
+    float* down[9] = {nullptr};
+    int cin = 2, r = 256;
+    for (int i = 1; i <= 8; ++i) {
+        const int c = kP2PDown[i - 1];
+        snprintf(n, sizeof n, "ws.p2p.down%d", i);
+        rc = dev_alloc(h, n, (size_t)B * (r / 2) * (r / 2) * c, false, &down[i]); if (rc) return rc;
+        Op op; op.type = OP_DIRECT; op.src_is_input = (i == 1);
+        DirectConvParams& p = op.dc;
+        p.in0 = i == 1 ? nullptr : down[i - 1]; p.c0 = cin; p.in1 = nullptr; p.c1 = 0;
+        snprintf(n, sizeof n, "p2p.down%d.kernel", i); p.w = D(h, n);
+        p.scale = p.shift = nullptr;
+        if (i > 1) {
+            snprintf(n, sizeof n, "p2p.down%d.bn", i);
+            float *sc, *sh; rc = fold_bn(n, c, &sc, &sh); if (rc) return rc;
+            p.scale = sc; p.shift = sh;
+        }
+        p.out = down[i]; p.out_c = c; p.out_coff = 0;
+        p.B = B; p.Hin = r; p.Win = r; p.Hout = r / 2; p.Wout = r / 2; p.Cout = c;
+        p.KH = 4; p.KW = 4; p.stride = 2; p.pad = 1; p.transposed = 0;
+        p.act = 2; p.slope = 0.3f;   // keras LeakyReLU() default alpha (pix2pix.py:72)
+        op.flops = 2.0 * B * (r / 2) * (r / 2) * 16.0 * cin * c;
+        h->ops.push_back(op);
+        cin = c; r /= 2;
+    }
+    float* x = down[8];
+    int c0 = 512, c1 = 0;
+    float* skip = nullptr;
+    for (int i = 1; i <= 7; ++i) {
+        const int c = kP2PUp[i - 1];
+        float* up;
+        snprintf(n, sizeof n, "ws.p2p.up%d", i);
+        rc = dev_alloc(h, n, (size_t)B * (2 * r) * (2 * r) * c, false, &up); if (rc) return rc;
+        Op op; op.type = OP_DIRECT;
+        DirectConvParams& p = op.dc;
+        p.in0 = x; p.c0 = c0; p.in1 = skip; p.c1 = c1;
+        snprintf(n, sizeof n, "p2p.up%d.kernel", i); p.w = D(h, n);
+        snprintf(n, sizeof n, "p2p.up%d.bn", i);
+        float *sc, *sh; rc = fold_bn(n, c, &sc, &sh); if (rc) return rc;
+        p.scale = sc; p.shift = sh;
+        p.out = up; p.out_c = c; p.out_coff = 0;
+        p.B = B; p.Hin = r; p.Win = r; p.Hout = 2 * r; p.Wout = 2 * r; p.Cout = c;
+        p.KH = 4; p.KW = 4; p.stride = 2; p.pad = 1; p.transposed = 1;
+        p.act = 1; p.slope = 0.f;
+        op.flops = 2.0 * B * r * r * 16.0 * (c0 + c1) * c;
+        h->ops.push_back(op);
+        x = up; c0 = c; skip = down[7 - (i - 1)]; c1 = kP2PDown[6 - (i - 1)];
+        r *= 2;
+    }
+    {
+        Op op; op.type = OP_DIRECT; op.out_is_output = true;
+        DirectConvParams& p = op.dc;
+        p.in0 = x; p.c0 = c0; p.in1 = skip; p.c1 = c1;
+        p.w = D(h, "p2p.last.kernel");
+        p.scale = nullptr;
+        rc = upload(h, "p2p.last.shift", h->host_small["p2p.last.bias"].data(), 1); if (rc) return rc;
+        p.shift = D(h, "p2p.last.shift");
+        p.out = nullptr; p.out_c = 1; p.out_coff = 0;
+        p.B = B; p.Hin = r; p.Win = r; p.Hout = 2 * r; p.Wout = 2 * r; p.Cout = 1;
+        p.KH = 4; p.KW = 4; p.stride = 2; p.pad = 1; p.transposed = 1;
+        p.act = 3; p.slope = 0.f;
+        op.flops = 2.0 * B * r * r * 16.0 * (c0 + c1) * 1;
+        h->ops.push_back(op);
+    }
+    return MSR_OK;
+}
+
+int ensure_plan(msr_handle* h) {
+    if (h->planned) return MSR_OK;
+    for (auto& s : h->specs)
+        if (!s.loaded) return fail(h, MSR_ERR_STATE, "weight '%s' has not been loaded", s.name.c_str());
+    h->ops.clear();
+    if (h->mom_partial) { hipFree(h->mom_partial); h->mom_partial = nullptr; }
+    if (h->dense_partial) { hipFree(h->dense_partial); h->dense_partial = nullptr; }
+    int rc = h->variant == MSR_PIX2PIX ? plan_pix2pix(h) : plan_spade(h);
+    if (rc) return rc;
+    h->fwd_flops = 0;
+    for (auto& op : h->ops) h->fwd_flops += op.flops;
+    HIPCHK(h, hipDeviceSynchronize());
+    h->planned = true;
+    return MSR_OK;
+}
+
+hipEvent_t get_event(msr_handle* h) {
+    if (h->ev_used == h->ev_pool.size()) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        h->ev_pool.push_back(e);
+    }
+    return h->ev_pool[h->ev_used++];
+}
+
+}  // namespace
+
+extern "C" {
+
+int msr_forward(msr_handle* h, const float* in_dev, const float* eps_dev, float* out_dev, int32_t batch,
+                void* stream_v) {
+    if (!h) return MSR_ERR_INVALID;
+    if (!in_dev || !out_dev) return fail(h, MSR_ERR_INVALID, "msr_forward: null tensor pointer");
+    if (batch != h->B)
+        return fail(h, MSR_ERR_INVALID, "batch %d != batch_size %d the handle was created with "
+                    "(the reference's sampler enforces the same, sampling.py:13-15)", batch, h->B);
+    if (h->variant == MSR_GAUGAN && !eps_dev)
+        return fail(h, MSR_ERR_INVALID, "variant gaugan needs the sampler noise eps [B, latent_dim]");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = ensure_plan(h);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream_v;
+    for (auto& op : h->ops) {
+        hipEvent_t ea = nullptr, eb = nullptr;
+        if (h->prof_on) { ea = get_event(h); eb = get_event(h); hipEventRecord(ea, s); }
+        hipError_t e = hipSuccess;
+        int fam = 0;
+        switch (op.type) {
+            case OP_CONV: fam = FAM_CONV; e = launch_conv_igemm(op.conv, op.epi, op.tile, s); break;
+            case OP_SMALLCIN: {
+                fam = FAM_SMALLCIN;
+                SmallCinParams p = op.sc;
+                if (op.src_is_input) p.src = in_dev;
+                e = launch_conv_smallcin(p, s);
+                break;
+            }
+            case OP_MOMENTS:
+                fam = FAM_MOMENTS;
+                e = launch_moments(op.mom.x, op.mom.G, op.mom.P, op.mom.C, op.mom.eps, h->mom_partial, op.mom.mean,
+                                   op.mom.stdv, s);
+                break;
+            case OP_NORMACT: fam = FAM_NORMACT; e = launch_norm_act(op.na, s); break;
+            case OP_DENSE:
+                fam = FAM_DENSE;
+                e = launch_dense(op.dense.x, op.dense.W, op.dense.bias, h->dense_partial, op.dense.y, op.dense.B,
+                                 op.dense.K, op.dense.N, s);
+                break;
+            case OP_LATENT:
+                fam = FAM_LATENT;
+                e = launch_latent(op.lat.mv, eps_dev, op.lat.z, op.lat.B, op.lat.L, op.lat.sampler, s);
+                break;
+            case OP_HEAD:
+                fam = FAM_HEAD;
+                e = launch_head(op.head.x, op.head.weff, op.head.bias, out_dev, op.head.B, op.head.r, op.head.C,
+                                op.head.slope, op.head.tanh_out, s);
+                break;
+            case OP_DIRECT: {
+                fam = FAM_DIRECT;
+                DirectConvParams p = op.dc;
+                if (op.src_is_input) p.in0 = in_dev;
+                if (op.out_is_output) p.out = out_dev;
+                e = launch_conv_direct(p, s);
+                break;
+            }
+        }
+        if (e != hipSuccess)
+            return fail(h, MSR_ERR_DEVICE, "launch of %s failed: %s", kFamilyName[fam], hipGetErrorString(e));
+        if (h->prof_on) { hipEventRecord(eb, s); h->prof.push_back({fam, ea, eb, op.flops, op.bytes}); }
+    }
+    return MSR_OK;
+}
+
+int msr_last_latent(msr_handle* h, float* z_dev, void* stream) {
+    if (!h || !z_dev) return MSR_ERR_INVALID;
+    if (!h->z) return fail(h, MSR_ERR_STATE, "no latent: run msr_forward on a SPADE variant first");
+    HIPCHK(h, hipMemcpyAsync(z_dev, h->z, (size_t)h->B * h->L * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return MSR_OK;
+}
+
+int msr_forward_flops(const msr_handle* hc, double* flops) {
+    msr_handle* h = const_cast<msr_handle*>(hc);
+    if (!h || !flops) return MSR_ERR_INVALID;
+    int rc = ensure_plan(h);
+    if (rc) return rc;
+    *flops = h->fwd_flops;
+    return MSR_OK;
+}
+
+int msr_debug_tensor(msr_handle* h, const char* name, float* host_out, int64_t count) {
+    if (!h || !name || !host_out) return MSR_ERR_INVALID;
+    auto it = h->dev.find(name);
+    if (it == h->dev.end()) return fail(h, MSR_ERR_INVALID, "no tensor named '%s'", name);
+    if (count < 0 || (size_t)count * sizeof(float) > h->dev_bytes[name])
+        return fail(h, MSR_ERR_INVALID, "%s holds %zu floats, %lld requested", name, h->dev_bytes[name] / sizeof(float),
+                    (long long)count);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(host_out, it->second, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
+    return MSR_OK;
+}
+
+int msr_device_bytes(const msr_handle* h, int64_t* bytes) {
+    if (!h || !bytes) return MSR_ERR_INVALID;
+    *bytes = (int64_t)h->total_bytes;
+    return MSR_OK;
+}
+
+int msr_profile_enable(msr_handle* h, int32_t on) {
+    if (!h) return MSR_ERR_INVALID;
+    h->prof_on = on != 0;
+    return MSR_OK;
+}
+
+int msr_profile_reset(msr_handle* h) {
+    if (!h) return MSR_ERR_INVALID;
+    hipDeviceSynchronize();
+    h->prof.clear();
+    h->ev_used = 0;
+    return MSR_OK;
+}
+
+int msr_profile_read(msr_handle* h, msr_kernel_stat* out, int32_t cap, int32_t* n) {
+    if (!h || !out || !n) return MSR_ERR_INVALID;
+    HIPCHK(h, hipDeviceSynchronize());
+    msr_kernel_stat st[FAM_COUNT];
+    std::memset(st, 0, sizeof st);
+    for (int f = 0; f < FAM_COUNT; ++f) std::snprintf(st[f].name, sizeof st[f].name, "%s", kFamilyName[f]);
+    for (auto& r : h->prof) {
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, r.a, r.b));
+        st[r.fam].launches += 1;
+        st[r.fam].device_ms += ms;
+        st[r.fam].flops += r.flops;
+        st[r.fam].bytes += r.bytes;
+    }
+    int k = 0;
+    for (int f = 0; f < FAM_COUNT && k < cap; ++f)
+        if (st[f].launches) out[k++] = st[f];
+    *n = k;
+    return MSR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tiler / stitcher
+// ------------------------------------------------------------------------------------------------
+int msr_patch_stats(msr_handle* h, const float* img, const float* dem, int32_t rows, int32_t cols, const int32_t* ox,
+                    const int32_t* oy, int32_t n, float no_value, uint8_t* valid, float* minmax, void* stream) {
+    if (!h) return MSR_ERR_INVALID;
+    if (!img || !dem || !ox || !oy || !valid || !minmax || n < 0 || rows <= 0 || cols <= 0)
+        return fail(h, MSR_ERR_INVALID, "msr_patch_stats: bad argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, launch_patch_stats(img, dem, rows, cols, ox, oy, n, h->S, no_value, valid, minmax, (hipStream_t)stream));
+    return MSR_OK;
+}
+
+int msr_extract_patches(msr_handle* h, const float* img, const float* dem, int32_t rows, int32_t cols,
+                        const int32_t* ox, const int32_t* oy, const float* minmax, int32_t n, float* out,
+                        void* stream) {
+    if (!h) return MSR_ERR_INVALID;
+    if (!img || !dem || !ox || !oy || !minmax || !out || n < 0)
+        return fail(h, MSR_ERR_INVALID, "msr_extract_patches: bad argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, launch_extract_patches(img, dem, rows, cols, ox, oy, minmax, n, h->S, out, (hipStream_t)stream));
+    return MSR_OK;
+}
+
+int msr_set_blend_window(msr_handle* h, const double* host_window, int32_t side) {
+    if (!h) return MSR_ERR_INVALID;
+    const int ws = h->S - 2 * (h->S / 16);
+    if (!host_window || side != ws) return fail(h, MSR_ERR_INVALID, "blend window must be [%d,%d] float64", ws, ws);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (!h->window) HIPCHK(h, hipMalloc(&h->window, (size_t)ws * ws * sizeof(double)));
+    HIPCHK(h, hipMemcpy(h->window, host_window, (size_t)ws * ws * sizeof(double), hipMemcpyHostToDevice));
+    return MSR_OK;
+}
+
+static int default_window(msr_handle* h) {
+    // makeGaussianKernel (process_full_tiles.py:347-361) + 1e-7, purged (:391-393), in float64 like NumPy.
+    const int S = h->S, p = S / 16, ws = S - 2 * p;
+    std::vector<double> ax(S), k((size_t)S * S);
+    const double start = -S / 2.0, stop = S / 2.0, step = (stop - start) / (S - 1);
+    for (int i = 0; i < S; ++i) ax[i] = i * step + start;
+    ax[S - 1] = stop;
+    const double sx = S / 5.0;
+    double mn = INFINITY, mx = -INFINITY;
+    for (int y = 0; y < S; ++y)
+        for (int x = 0; x < S; ++x) {
+            const double v = 1.0 / (2.0 * M_PI * sx * sx) *
+                             std::exp(-(std::pow(ax[x] - 0, 2.0) / (2.0 * std::pow(sx, 2.0)) +
+                                        std::pow(ax[y] - 0, 2.0) / (2.0 * std::pow(sx, 2.0))));
+            k[(size_t)y * S + x] = v;
+            mn = std::min(mn, v); mx = std::max(mx, v);
+        }
+    std::vector<double> w((size_t)ws * ws);
+    for (int y = 0; y < ws; ++y)
+        for (int x = 0; x < ws; ++x) w[(size_t)y * ws + x] = (k[(size_t)(y + p) * S + x + p] - mn) / (mx - mn) + 1e-7;
+    return msr_set_blend_window(h, w.data(), ws);
+}
+
+int msr_stitch_tile(msr_handle* h, const float* pred, const int32_t* key, const float* dmm, int32_t n,
+                    int32_t tile_size, int32_t stride, float no_value, int32_t as_implemented, float* mean,
+                    float* stdv, uint8_t* good, void* stream) {
+    if (!h) return MSR_ERR_INVALID;
+    if (!mean || !stdv || !good || n < 0 || (n > 0 && (!pred || !key || !dmm)))
+        return fail(h, MSR_ERR_INVALID, "msr_stitch_tile: null pointer");
+    if (tile_size <= 0 || stride <= 0 || stride > h->S)
+        return fail(h, MSR_ERR_INVALID, "msr_stitch_tile: tile_size %d / stride %d invalid for image_size %d", tile_size,
+                    stride, h->S);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (!h->window) { int rc = default_window(h); if (rc) return rc; }
+    const int NG = (tile_size + h->S - 1) / stride;
+    if (NG * NG > h->stitch_grid_cap) {
+        if (h->stitch_grid) HIPCHK(h, hipFree(h->stitch_grid));
+        HIPCHK(h, hipMalloc(&h->stitch_grid, (size_t)NG * NG * sizeof(int)));
+        h->stitch_grid_cap = NG * NG;
+    }
+    HIPCHK(h, launch_stitch_tile(pred, key, dmm, n, h->S, tile_size, stride, no_value, as_implemented, h->window,
+                                 h->stitch_grid, mean, stdv, good, (hipStream_t)stream));
+    return MSR_OK;
+}
+
+}  // extern "C"

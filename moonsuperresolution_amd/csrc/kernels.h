@@ -1,0 +1,132 @@
+// Internal launch interface between the C-ABI layer (api.hip) and the gfx950 kernels.
+// Everything here is MI355X-only HIP; there is no other backend.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace msr {
+
+// ---------------------------------------------------------------------------------------------
+// conv_igemm_f32: NHWC implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 (exact fp32).
+//   M = B*Hout*Wout output pixels, N = output channels, K = KH*KW*Cin.
+// The input is a physically zero-padded NHWC tensor, so the K loop has no bounds checks:
+//   in[(b*in_pb) + (y*stride + kh)*in_py + (x*stride + kw)*Cin + c]  is tap (kh,kw) of output (y,x).
+// Weights are pre-laid-out [KH*KW][N][Cin] (K contiguous per output channel).
+// ---------------------------------------------------------------------------------------------
+enum ConvEpilogue : int {
+    EPI_BIAS = 0,   // out = acc + bias                       (encoder convs pass bias = zeros)
+    EPI_RES = 1,    // out = acc + bias + aux[(y>>s),(x>>s)]  (ResidualBlock skip add, blocks.py:38,
+                    //                                          with UpSampling2D folded into the index)
+    EPI_SPADE = 2,  // N = 2C, columns interleaved (gamma block of 32 | beta block of 32):
+                    // out = leaky_relu((g+bg) * ((x-mean)/std) + (b+bb))   spade.py:21-24 + blocks.py:30-34
+};
+
+struct ConvParams {
+    const float* in;
+    const float* wt;
+    const float* bias;    // [N] in GEMM column order
+    float* out;
+    const float* aux;     // EPI_RES: residual; EPI_SPADE: x (the tensor being normalised)
+    const float* mean;    // EPI_SPADE: [C]
+    const float* stdv;    // EPI_SPADE: [C]  sqrt(var + eps)
+    int B, Hout, Wout, Cin, N;
+    int KH, KW, stride;
+    int in_py, in_pb;             // input pitches in floats (pixel pitch = Cin)
+    int out_px, out_py, out_pb;   // output pitches in floats
+    int out_off;                  // offset of output pixel (0,0) channel 0 of sample 0
+    int aux_px, aux_py, aux_pb;   // aux pitches
+    int aux_shift;                // 1 = aux is at half resolution (nearest 2x up-sample folded in)
+    float slope;                  // leaky-relu slope of EPI_SPADE
+};
+
+enum ConvTile : int { TILE_128x128 = 0, TILE_64x64 = 1 };
+
+hipError_t conv_igemm_init();   // sets dynamic-LDS attributes once
+hipError_t launch_conv_igemm(const ConvParams& p, int epilogue, int tile, hipStream_t s);
+// picks the tile for a problem size (fills the chip for the low-resolution layers)
+int conv_pick_tile(int M, int N);
+
+// ---------------------------------------------------------------------------------------------
+// Small kernels (memory-bound or tiny)
+// ---------------------------------------------------------------------------------------------
+// Direct 3x3 conv from the 2-channel source: SPADE mask embedding fused with the half-pixel
+// nearest resize (spade.py:17-18) and the first encoder block (networks.py:16-18).
+//   t = y*ay + kh + cy (valid iff 0 <= t < lim); source row = t*f + o.  Same along x.
+struct SmallCinParams {
+    const float* src;   // [B,S,S,2]
+    const float* w;     // HWIO [3,3,2,Cout]
+    const float* bias;  // [Cout] or nullptr
+    float* out;
+    int B, S, Hout, Cout;
+    int ay, cy, lim, f, o;
+    int out_px, out_py, out_pb, out_off;
+    int act;            // 0 none, 1 relu, 2 leaky(slope)
+    float slope;
+};
+hipError_t launch_conv_smallcin(const SmallCinParams& p, hipStream_t s);
+
+// Per-group, per-channel moments of x [G, P, C]: mean and sqrt(var_biased + eps) (fp64 accumulation).
+//   G=1 -> tf.nn.moments over (N,H,W) (spade.py:21);  G=B -> tfa InstanceNormalization (blocks.py:63).
+// partial must hold G * chunks * C * 2 doubles with chunks = moments_chunks(P).
+int moments_chunks(int P);
+hipError_t launch_moments(const float* x, int G, int P, int C, float eps, double* partial, float* mean,
+                          float* stdv, hipStream_t s);
+
+// out = act(((x - mean[g,c]) / std[g,c]) * gamma[c] + beta[c]) written with arbitrary output pitches.
+struct NormActParams {
+    const float* x;       // [B, H, W, C] dense
+    const float* mean;    // [B, C]
+    const float* stdv;    // [B, C]
+    const float* gamma;   // [C]
+    const float* beta;    // [C]
+    float* out;
+    int B, H, W, C;
+    int out_px, out_py, out_pb, out_off;
+    float slope;
+};
+hipError_t launch_norm_act(const NormActParams& p, hipStream_t s);
+
+// y[b, n] = sum_k x[b, k] * W[k, n] (+ bias) for tiny M = B <= 16: split-K weight streaming.
+int dense_splits(int K);
+hipError_t launch_dense(const float* x, const float* W, const float* bias, float* partial, float* y, int B, int K,
+                        int N, hipStream_t s);
+
+// z = mean + exp(0.5*var)*eps (sampling.py:16) or mean + var (model.py:267); mv = [B, 2*L] (mean | var).
+hipError_t launch_latent(const float* mv, const float* eps, float* z, int B, int L, int use_sampler,
+                         hipStream_t s);
+
+// Head: leaky_relu -> UpSampling2D(2) -> Conv2D(1, 4, 'same') (+tanh) fused (networks.py:54-56).
+//   x [B, r, r, C] at half resolution, weff = [2][2][3][3][C] effective per-parity weights, out [B, 2r, 2r].
+hipError_t launch_head(const float* x, const float* weff, float bias, float* out, int B, int r, int C,
+                       float slope, int tanh_out, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// Generic direct convolution (pix2pix plumbing config: Conv2D / Conv2DTranspose 4x4 s2, BN, act, concat)
+// ---------------------------------------------------------------------------------------------
+struct DirectConvParams {
+    const float* in0; int c0;     // first input [B,Hin,Win,c0]
+    const float* in1; int c1;     // optional second input (channel concat), c1 = 0 if none
+    const float* w;               // conv: [KH,KW,Cin,Cout]; transposed: [KH,KW,Cout,Cin]
+    const float* scale;           // per-Cout affine (folded BN) or nullptr
+    const float* shift;           // per-Cout shift (folded BN / bias) or nullptr
+    float* out; int out_c, out_coff;  // output pixel pitch and channel offset (for writing into a concat buffer)
+    int B, Hin, Win, Hout, Wout, Cout;
+    int KH, KW, stride, pad;      // pad = padding before (TF SAME)
+    int transposed;
+    int act;                      // 0 none, 1 relu, 2 leaky, 3 tanh
+    float slope;
+};
+hipError_t launch_conv_direct(const DirectConvParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// Tiler / stitcher
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_patch_stats(const float* img, const float* dem, int rows, int cols, const int* ox, const int* oy,
+                              int n, int S, float no_value, uint8_t* valid, float* minmax, hipStream_t s);
+hipError_t launch_extract_patches(const float* img, const float* dem, int rows, int cols, const int* ox,
+                                  const int* oy, const float* minmax, int n, int S, float* out, hipStream_t s);
+hipError_t launch_stitch_tile(const float* pred, const int* key, const float* dmm, int n, int S, int T, int stride,
+                              float no_value, int as_implemented, const double* window, int* grid_ws,
+                              float* mean, float* stdv, uint8_t* good, hipStream_t s);
+
+}  // namespace msr

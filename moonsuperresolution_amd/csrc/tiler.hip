@@ -1,0 +1,188 @@
+// Tiler / stitcher kernels: the NumPy half of the reference's driver (process_full_tiles.py) on the GPU.
+// Compiled with -ffp-contract=off: every float op below mirrors one NumPy op of the reference, evaluated in
+// the same type (float32 or float64) and the same order, so results are bit-exact with the CPU path.
+#include "kernels.h"
+
+namespace msr {
+
+// ------------------------------------------------------------------------------------------------
+// patch_stats: getPatch's validity test + normalize's four reductions for every patch of a tile
+// (process_full_tiles.py:286-292, 307-309).  One workgroup per patch; min/max are exact.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) patch_stats_kernel(const float* __restrict__ img, const float* __restrict__ dem,
+                                                          int rows, int cols, const int* __restrict__ ox,
+                                                          const int* __restrict__ oy, int S, float no_value,
+                                                          uint8_t* __restrict__ valid, float* __restrict__ minmax) {
+    __shared__ float red[4][4];
+    __shared__ int bad[4];
+    const int i = blockIdx.x;
+    const int x0 = ox[i], y0 = oy[i];
+    float imn = INFINITY, imx = -INFINITY, dmn = INFINITY, dmx = -INFINITY;
+    int anybad = 0;
+    if (x0 < 0 || y0 < 0 || x0 + S > cols || y0 + S > rows) {
+        anybad = 1;   // outside the canvas: not a patch the reference could cut
+    } else {
+        const int qpr = S / 4;   // float4 per patch row (S is a multiple of 64)
+        const bool aligned = ((x0 & 3) == 0) && ((cols & 3) == 0);
+        for (int e = threadIdx.x; e < S * qpr; e += 256) {
+            const int y = e / qpr, q = e % qpr;
+            const size_t off = (size_t)(y0 + y) * cols + x0 + q * 4;
+            float4 a, d;
+            if (aligned) {
+                a = *reinterpret_cast<const float4*>(img + off);
+                d = *reinterpret_cast<const float4*>(dem + off);
+            } else {
+                a = make_float4(img[off], img[off + 1], img[off + 2], img[off + 3]);
+                d = make_float4(dem[off], dem[off + 1], dem[off + 2], dem[off + 3]);
+            }
+            imn = fminf(fminf(imn, a.x), fminf(fminf(a.y, a.z), a.w));
+            imx = fmaxf(fmaxf(imx, a.x), fmaxf(fmaxf(a.y, a.z), a.w));
+            dmn = fminf(fminf(dmn, d.x), fminf(fminf(d.y, d.z), d.w));
+            dmx = fmaxf(fmaxf(dmx, d.x), fmaxf(fmaxf(d.y, d.z), d.w));
+            anybad |= (a.x <= no_value) | (a.y <= no_value) | (a.z <= no_value) | (a.w <= no_value) |
+                      (d.x <= no_value) | (d.y <= no_value) | (d.z <= no_value) | (d.w <= no_value);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        imn = fminf(imn, __shfl_xor(imn, o));
+        imx = fmaxf(imx, __shfl_xor(imx, o));
+        dmn = fminf(dmn, __shfl_xor(dmn, o));
+        dmx = fmaxf(dmx, __shfl_xor(dmx, o));
+        anybad |= __shfl_xor(anybad, o);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[wave][0] = imn; red[wave][1] = imx; red[wave][2] = dmn; red[wave][3] = dmx;
+        bad[wave] = anybad;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            red[0][0] = fminf(red[0][0], red[w][0]); red[0][1] = fmaxf(red[0][1], red[w][1]);
+            red[0][2] = fminf(red[0][2], red[w][2]); red[0][3] = fmaxf(red[0][3], red[w][3]);
+            bad[0] |= bad[w];
+        }
+        valid[i] = bad[0] ? 0 : 1;
+        minmax[4 * i + 0] = red[0][0]; minmax[4 * i + 1] = red[0][1];
+        minmax[4 * i + 2] = red[0][2]; minmax[4 * i + 3] = red[0][3];
+    }
+}
+
+hipError_t launch_patch_stats(const float* img, const float* dem, int rows, int cols, const int* ox, const int* oy,
+                              int n, int S, float no_value, uint8_t* valid, float* minmax, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    patch_stats_kernel<<<n, 256, 0, s>>>(img, dem, rows, cols, ox, oy, S, no_value, valid, minmax);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// extract_patches: normalize (process_full_tiles.py:307-310): ((p - min) / (max - min)) - 0.5 in float32,
+// channel 0 = ortho, 1 = DEM.  Origin (-1,-1) = the zero padding patch of :468-474.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) extract_patches_kernel(const float* __restrict__ img,
+                                                              const float* __restrict__ dem, int cols,
+                                                              const int* __restrict__ ox, const int* __restrict__ oy,
+                                                              const float* __restrict__ minmax, int S,
+                                                              float* __restrict__ out) {
+    const int i = blockIdx.y;
+    const int x0 = ox[i], y0 = oy[i];
+    float2* o = reinterpret_cast<float2*>(out) + (size_t)i * S * S;
+    const bool pad = x0 < 0 || y0 < 0;
+    const float imn = minmax[4 * i + 0], imx = minmax[4 * i + 1], dmn = minmax[4 * i + 2], dmx = minmax[4 * i + 3];
+    const float irange = imx - imn, drange = dmx - dmn;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < S * S; e += gridDim.x * 256) {
+        float2 v = make_float2(0.f, 0.f);
+        if (!pad) {
+            const int y = e / S, x = e % S;
+            const size_t off = (size_t)(y0 + y) * cols + x0 + x;
+            v.x = (img[off] - imn) / irange - 0.5f;
+            v.y = (dem[off] - dmn) / drange - 0.5f;
+        }
+        o[e] = v;
+    }
+}
+
+hipError_t launch_extract_patches(const float* img, const float* dem, int rows, int cols, const int* ox,
+                                  const int* oy, const float* minmax, int n, int S, float* out, hipStream_t s) {
+    (void)rows;
+    if (n <= 0) return hipSuccess;
+    int bx = (S * S + 255) / 256;
+    if (bx > 64) bx = 64;
+    extract_patches_kernel<<<dim3(bx, n), 256, 0, s>>>(img, dem, cols, ox, oy, minmax, S, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// stitch_tile: rebuildTile (process_full_tiles.py:363-414) as a GATHER: one thread per output pixel of the
+// cropped [T,T] tile walks the <= ((S-2p)/s)^2 patches covering it in generation order (y outer, x inner —
+// the insertion order of the reference's dict) and applies the weighted incremental update in registers.
+// No atomics, no accumulator images in HBM, deterministic, same summation order as the reference.
+// Types follow NumPy: window float64, accumulators float32, each update evaluated in float64 and rounded
+// to float32 on store.  as_implemented reproduces the aliasing of :400-402 (S += w*(x-mean_new)^2).
+// ------------------------------------------------------------------------------------------------
+__global__ void stitch_grid_kernel(const int* __restrict__ key, int n, int stride, int NG, int* __restrict__ grid) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int kx = key[2 * i], ky = key[2 * i + 1];
+    if (kx < 0 || ky < 0 || kx % stride || ky % stride) return;
+    const int gx = kx / stride, gy = ky / stride;
+    if (gx < NG && gy < NG) grid[gy * NG + gx] = i;
+}
+
+__global__ void __launch_bounds__(256) stitch_tile_kernel(const float* __restrict__ pred, const float* __restrict__ dmm,
+                                                          const int* __restrict__ grid, int NG, int S, int T,
+                                                          int stride, float no_value, int as_implemented,
+                                                          const double* __restrict__ window, float* __restrict__ mean_o,
+                                                          float* __restrict__ std_o, uint8_t* __restrict__ good_o) {
+    const int tx = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int ty = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (tx >= T || ty >= T) return;
+    const int halo = S - stride, purge = S / 16, ws = S - 2 * purge;
+    const int ax = tx + halo, ay = ty + halo;
+    // patches with ky in (ay - S + purge, ay - purge]
+    auto lo_idx = [&](int a) { int v = a - S + purge + 1; return v <= 0 ? 0 : (v + stride - 1) / stride; };
+    auto hi_idx = [&](int a) { int v = a - purge; return v < 0 ? -1 : min(v / stride, NG - 1); };
+    const int gy0 = lo_idx(ay), gy1 = hi_idx(ay), gx0 = lo_idx(ax), gx1 = hi_idx(ax);
+    float w_sum = 0.f, mean = 0.f, s_acc = 0.f;
+    for (int gy = gy0; gy <= gy1; ++gy) {
+        const int py = ay - gy * stride;
+        for (int gx = gx0; gx <= gx1; ++gx) {
+            const int slot = grid[gy * NG + gx];
+            if (slot < 0) continue;
+            const int px = ax - gx * stride;
+            const float pr = pred[(size_t)slot * S * S + (size_t)py * S + px] + 0.5f;       // :340
+            const float lo = dmm[2 * slot], hi = dmm[2 * slot + 1];
+            const float xval = pr * (hi - lo) + lo;                                          // :395
+            const double w = window[(size_t)(py - purge) * ws + (px - purge)];
+            w_sum = (float)((double)w_sum + w);                                              // :397
+            const float d_old = xval - mean;
+            const float mean_new = (float)((double)mean + (w / (double)w_sum) * (double)d_old);   // :401
+            const float d_new = xval - mean_new;
+            const double first = as_implemented ? (double)d_new : (double)d_old;
+            s_acc = (float)((double)s_acc + (w * first) * (double)d_new);                    // :402
+            mean = mean_new;
+        }
+    }
+    const bool good = w_sum > 0.f;                                                           // :409
+    const float sd = sqrtf(s_acc / w_sum);                                                   // :411
+    const size_t o = (size_t)ty * T + tx;
+    mean_o[o] = good ? mean : no_value;
+    std_o[o] = good ? sd : no_value;
+    good_o[o] = good ? 1 : 0;
+}
+
+hipError_t launch_stitch_tile(const float* pred, const int* key, const float* dmm, int n, int S, int T, int stride,
+                              float no_value, int as_implemented, const double* window, int* grid_ws, float* mean,
+                              float* stdv, uint8_t* good, hipStream_t s) {
+    const int NG = (T + S - 1) / stride;   // len(range(0, T + S - stride, stride))
+    hipError_t e = hipMemsetAsync(grid_ws, 0xFF, sizeof(int) * NG * NG, s);
+    if (e != hipSuccess) return e;
+    if (n > 0) stitch_grid_kernel<<<(n + 255) / 256, 256, 0, s>>>(key, n, stride, NG, grid_ws);
+    stitch_tile_kernel<<<dim3((T + 15) / 16, (T + 15) / 16), 256, 0, s>>>(pred, dmm, grid_ws, NG, S, T, stride,
+                                                                         no_value, as_implemented, window, mean,
+                                                                         stdv, good);
+    return hipGetLastError();
+}
+
+}  // namespace msr

@@ -1,0 +1,165 @@
+"""``Generator`` — the drop-in for the reference's ``model`` callable.
+
+The reference's only coupling between its inference driver and its networks is
+``pred_dems = self.model(np.array(batch), training=False)`` (process_full_tiles.py:338) followed by
+``np.array(pred_dems)[:, :, :, -1] + 0.5`` (:340), where ``model`` is ``GauGAN(image_size, batch_size,
+latent_dim)`` / ``CNNSpade(...)`` (process_full_tiles.py:28,48) or ``Pix2Pix().generator``.  This class keeps
+that signature — ``Generator(image_size, batch_size, ...)(batch[B,S,S,2], training=False) ->
+np.ndarray[B,S,S,1]`` — and runs the hand-written gfx950 kernels of libmoonsr_hip.so underneath.
+
+PyTorch is used for device memory and streams only; all arithmetic happens inside the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Mapping, Optional, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from .weights import VARIANTS, make_latent_noise, make_weights, weight_shapes
+
+
+class Generator:
+    """MI355X generator(call).
+
+    Args mirror ``GauGAN(image_size, batch_size, latent_dim=256)`` (spade/models/model.py:341-346):
+        image_size, batch_size, latent_dim: as the reference; ``batch_size`` is baked in, like the
+            reference's sampler (spade/models/sampling.py:13-15).
+        variant: "gaugan" (sampler), "gaugan_no_kl" / "cnn" (mean + variance), "pix2pix".
+        weights: name -> float32 array in the reference layouts (see ``weights.weight_shapes``), or an int
+            seed for the Keras-default random init (no trained weights ship with the reference).
+        eps: the sampler's N(0,1) draw ``[batch_size, latent_dim]`` for "gaugan"; ``None`` draws a fresh one
+            per call like ``tf.random.normal`` (sampling.py:13), an int seeds a fixed one (repeatable runs).
+        device: HIP device ordinal (one process per GPU).
+    """
+
+    def __init__(self, image_size: int, batch_size: int, latent_dim: int = 256, variant: str = "gaugan",
+                 weights: Union[int, Mapping[str, np.ndarray]] = 1234, eps: Union[None, int, np.ndarray] = None,
+                 device: int = 0):
+        if variant not in VARIANTS:
+            raise ValueError(f"unknown variant {variant!r}; expected one of {VARIANTS}")
+        self.image_size, self.batch_size, self.latent_dim, self.variant = image_size, batch_size, latent_dim, variant
+        self._lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("moonsuperresolution_amd needs a HIP device (MI355X / gfx950); there is no CPU fallback")
+        self.device = torch.device("cuda", device)
+        cfg = _lib.MsrConfig(image_size, batch_size, latent_dim, _lib.VARIANT_IDS[variant], device, 0)
+        handle = C.c_void_p()
+        rc = self._lib.msr_create(C.byref(cfg), C.byref(handle))
+        _lib.raise_for(self._lib, None, rc, "msr_create")
+        self._h = handle
+        self._eps_mode = eps
+        self._eps_fixed: Optional[torch.Tensor] = None
+        if isinstance(eps, (int, np.integer)):
+            self._eps_fixed = torch.from_numpy(make_latent_noise(batch_size, latent_dim, int(eps))).to(self.device)
+        elif eps is not None:
+            e = np.ascontiguousarray(eps, dtype=np.float32)
+            if e.shape != (batch_size, latent_dim):
+                raise ValueError(f"eps must be [{batch_size}, {latent_dim}], got {e.shape}")
+            self._eps_fixed = torch.from_numpy(e).to(self.device)
+        if isinstance(weights, (int, np.integer)):
+            weights = make_weights(variant, image_size, latent_dim, seed=int(weights))
+        self.load(weights)
+
+    # -- weights -----------------------------------------------------------------------------------
+    def load(self, weights: Mapping[str, np.ndarray]) -> None:
+        """Counterpart of ``gaugan.load(...)`` (process_full_tiles.py:30): takes a name -> array dict."""
+        expected = weight_shapes(self.variant, self.image_size, self.latent_dim)
+        missing = [k for k in expected if k not in weights]
+        if missing:
+            raise ValueError(f"missing weights: {missing[:5]}{' ...' if len(missing) > 5 else ''}")
+        for name, shape in expected.items():
+            a = np.ascontiguousarray(weights[name], dtype=np.float32)
+            if tuple(a.shape) != tuple(shape):
+                raise ValueError(f"weight {name}: shape {a.shape}, expected {shape}")
+            shp = (C.c_int64 * a.ndim)(*a.shape)
+            rc = self._lib.msr_load_weight(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), shp, a.ndim)
+            _lib.raise_for(self._lib, self._h, rc, f"msr_load_weight({name})")
+
+    # -- the call ------------------------------------------------------------------------------------
+    def forward_device(self, batch: torch.Tensor, eps: Optional[torch.Tensor] = None,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Device fast path: ``batch`` [B,S,S,2] float32 on this GPU -> [B,S,S,1] on the GPU (no host copy).
+
+        Asynchronous on torch's current stream."""
+        S, B = self.image_size, self.batch_size
+        if tuple(batch.shape) != (B, S, S, 2):
+            raise ValueError(f"expected a batch of shape {(B, S, S, 2)} (batch_size is fixed at construction, "
+                             f"like the reference's sampler), got {tuple(batch.shape)}")
+        if batch.device != self.device or batch.dtype != torch.float32 or not batch.is_contiguous():
+            batch = batch.to(device=self.device, dtype=torch.float32).contiguous()
+        if out is None:
+            out = torch.empty((B, S, S, 1), dtype=torch.float32, device=self.device)
+        eps_ptr = None
+        if self.variant == "gaugan":
+            if eps is None:
+                eps = self._eps_fixed
+            if eps is None:
+                eps = torch.randn((B, self.latent_dim), dtype=torch.float32, device=self.device)
+            eps = eps.to(device=self.device, dtype=torch.float32).contiguous()
+            eps_ptr = eps.data_ptr()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self._lib.msr_forward(self._h, batch.data_ptr(), eps_ptr, out.data_ptr(), B, stream)
+        _lib.raise_for(self._lib, self._h, rc, "msr_forward")
+        return out
+
+    def __call__(self, batch, training: bool = False) -> np.ndarray:
+        """``model(np.array(batch), training=False)`` of process_full_tiles.py:338.
+
+        ``training`` is accepted for signature parity; the SPADE inference path has no mode-dependent layer
+        and pix2pix runs its BatchNorm on moving statistics with dropout off (training=False semantics)."""
+        if training:
+            raise ValueError("this is the inference path: training=True is not supported")
+        x = torch.from_numpy(np.ascontiguousarray(np.asarray(batch), dtype=np.float32))
+        with torch.cuda.device(self.device):
+            y = self.forward_device(x.to(self.device, non_blocking=False))
+            return y.cpu().numpy()
+
+    def last_latent(self) -> np.ndarray:
+        z = torch.empty((self.batch_size, self.latent_dim), dtype=torch.float32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self._lib.msr_last_latent(self._h, z.data_ptr(), stream)
+        _lib.raise_for(self._lib, self._h, rc, "msr_last_latent")
+        return z.cpu().numpy()
+
+    def debug_tensor(self, name: str, shape) -> np.ndarray:
+        """Copy a named workspace tensor of the last call to the host (per-block parity tests)."""
+        out = np.empty(shape, np.float32)
+        rc = self._lib.msr_debug_tensor(self._h, name.encode(), out.ctypes.data_as(C.c_void_p), out.size)
+        _lib.raise_for(self._lib, self._h, rc, f"msr_debug_tensor({name})")
+        return out
+
+    # -- measurement ---------------------------------------------------------------------------------
+    def forward_flops(self) -> float:
+        v = C.c_double()
+        _lib.raise_for(self._lib, self._h, self._lib.msr_forward_flops(self._h, C.byref(v)), "msr_forward_flops")
+        return v.value
+
+    def device_bytes(self) -> int:
+        v = C.c_int64()
+        _lib.raise_for(self._lib, self._h, self._lib.msr_device_bytes(self._h, C.byref(v)), "msr_device_bytes")
+        return v.value
+
+    def profile(self, on: bool) -> None:
+        self._lib.msr_profile_enable(self._h, 1 if on else 0)
+        self._lib.msr_profile_reset(self._h)
+
+    def profile_read(self) -> Dict[str, dict]:
+        arr = (_lib.MsrKernelStat * 16)()
+        n = C.c_int32()
+        _lib.raise_for(self._lib, self._h, self._lib.msr_profile_read(self._h, arr, 16, C.byref(n)), "msr_profile_read")
+        return {arr[i].name.decode(): dict(launches=arr[i].launches, device_ms=arr[i].device_ms, flops=arr[i].flops,
+                                           bytes=arr[i].bytes) for i in range(n.value)}
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.msr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,184 @@
+"""ORACLE (test infrastructure, never shipped, never on the product path).
+
+NumPy restatement of the tiling / stitching half of the reference's inference driver
+(``DEMSuperResolution`` in process_full_tiles.py).  Each function cites the lines it follows.
+
+Pinned by the reference's only built-in known-answer check, the identity model
+(process_full_tiles.py:139-143): with ``model = lambda x, training=False: x`` the stitched ``mean``
+must reproduce the input DEM wherever ``good == 1`` and ``std`` must be ~0
+(tests/test_oracle_tiler.py).  The generator itself stays "parity unpinned" (oracle/generator_ref.py).
+
+Arithmetic notes that a bit-exact GPU stitcher must reproduce:
+* the blending window is float64 (np.linspace), the accumulators float32: every update is evaluated
+  in float64 and rounded to float32 on store;
+* ``mean_old`` at process_full_tiles.py:400 is a *view* of ``mean``; after the in-place store at :401
+  it already holds the new mean, so :402 accumulates ``S += w * (x - mean_new)**2`` (not West's
+  ``(x - mean_old) * (x - mean_new)``).  ``as_implemented=False`` gives the textbook form.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Tuple
+
+import numpy as np
+
+
+def identity_model(x, training=False):
+    """process_full_tiles.py:143 default model."""
+    return x
+
+
+def padded_canvas_shape(shape: Tuple[int, int], image_size: int, stride: int) -> Tuple[int, int]:
+    """process_full_tiles.py:252-253 (the 1024 is hard-coded there, independent of tile_size)."""
+    h, w = shape
+    halo = image_size - stride
+    return ((h // 1024) + 1) * 1024 + 2 * halo, ((w // 1024) + 1) * 1024 + 2 * halo
+
+
+def pad_inputs(img: np.ndarray, dem: np.ndarray, image_size: int, stride: int, no_value: float):
+    """padInputs, process_full_tiles.py:246-267: no_value canvas, data at offset (S - s)."""
+    assert img.shape == dem.shape
+    halo = image_size - stride
+    hp, wp = padded_canvas_shape(dem.shape, image_size, stride)
+    img_p = np.full((hp, wp), no_value, np.float32)
+    dem_p = np.full((hp, wp), no_value, np.float32)
+    img_p[halo:halo + dem.shape[0], halo:halo + dem.shape[1]] = img
+    dem_p[halo:halo + dem.shape[0], halo:halo + dem.shape[1]] = dem
+    return img_p, dem_p
+
+
+def tile_list(shape: Tuple[int, int], tile_size: int) -> List[Tuple[int, int]]:
+    """generateTileList, process_full_tiles.py:313-325: (xx, yy), y outer, over the UN-padded extent."""
+    return [(xx, yy) for yy in range(0, shape[0], tile_size) for xx in range(0, shape[1], tile_size)]
+
+
+def patch_origins(px: int, py: int, tile_size: int, image_size: int, stride: int):
+    """The double loop of processTile, process_full_tiles.py:453-454 (row-major, y outer)."""
+    span = tile_size + image_size - stride
+    return [(xx, yy) for yy in range(py, py + span, stride) for xx in range(px, px + span, stride)]
+
+
+def get_patch(img_p, dem_p, px: int, py: int, image_size: int, no_value: float):
+    """getPatch, process_full_tiles.py:269-293: invalid if ANY pixel <= no_value in ortho or DEM."""
+    ip = img_p[py:py + image_size, px:px + image_size]
+    dp = dem_p[py:py + image_size, px:px + image_size]
+    valid = not ((ip <= no_value).any() or (dp <= no_value).any())
+    return valid, ip, dp
+
+
+def normalize(ip: np.ndarray, dp: np.ndarray):
+    """normalize, process_full_tiles.py:295-311: per-patch min-max to [-0.5, 0.5]; channel 0 ortho, 1 DEM."""
+    i_n = (ip - ip.min()) / (ip.max() - ip.min()) - 0.5
+    mm = (dp.min(), dp.max())
+    d_n = (dp - dp.min()) / (dp.max() - dp.min()) - 0.5
+    return np.stack([i_n, d_n], axis=-1), mm
+
+
+def gaussian_window(image_size: int) -> np.ndarray:
+    """makeGaussianKernel, process_full_tiles.py:347-361: isotropic, sigma = S/5, min-max to [0,1], float64."""
+    s = image_size / 5
+    ax = np.linspace(-image_size / 2, image_size / 2, image_size)
+    xx, yy = np.meshgrid(ax, ax)
+    k = 1.0 / (2.0 * np.pi * s * s) * np.exp(-((xx - 0) ** 2.0 / (2.0 * s ** 2.0) + (yy - 0) ** 2.0 / (2.0 * s ** 2.0)))
+    return (k - k.min()) / (k.max() - k.min())
+
+
+def blend_window(image_size: int) -> np.ndarray:
+    """The window as rebuildTile uses it (process_full_tiles.py:391-393): +1e-7, purge S//16 per side."""
+    p = image_size // 16
+    return (gaussian_window(image_size) + 1e-7)[p:-p, p:-p]
+
+
+def rebuild_tile(generated: Dict[Tuple[int, int], np.ndarray], minmax: Dict[Tuple[int, int], Tuple[float, float]],
+                 tile_size: int, image_size: int, stride: int, no_value: float, as_implemented: bool = True):
+    """rebuildTile, process_full_tiles.py:363-414: Gaussian-weighted incremental mean / variance.
+
+    ``generated`` must iterate in insertion (= generation) order, like the reference's dict.
+    Returns (mean f32 [T,T], std f32 [T,T], good u8 [T,T]).
+    """
+    halo = image_size - stride
+    n = tile_size + 2 * halo
+    w_sum = np.zeros((n, n), np.float32)
+    mean = np.zeros((n, n), np.float32)
+    s_acc = np.zeros((n, n), np.float32)
+    w = blend_window(image_size)
+    p = image_size // 16
+    for (kx, ky), pred in generated.items():
+        lo, hi = minmax[(kx, ky)]
+        x = (pred * (hi - lo) + lo)[p:-p, p:-p]
+        ys = slice(ky + p, ky + image_size - p)
+        xs = slice(kx + p, kx + image_size - p)
+        w_sum[ys, xs] += w
+        old = mean[ys, xs].copy()
+        mean[ys, xs] = old + (w / w_sum[ys, xs]) * (x - old)
+        first = (x - mean[ys, xs]) if as_implemented else (x - old)
+        s_acc[ys, xs] += w * first * (x - mean[ys, xs])
+    crop = slice(halo, n - halo)
+    w_sum, mean, s_acc = w_sum[crop, crop], mean[crop, crop].copy(), s_acc[crop, crop]
+    good = (w_sum > 0) * 1.0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        std = np.sqrt(s_acc / w_sum)
+    mean[good == 0] = no_value
+    std[good == 0] = no_value
+    return mean, std, good.astype(np.uint8)
+
+
+def run_batch(model: Callable, batch: List[np.ndarray], index: List[Tuple[int, int]], out: dict) -> None:
+    """processBatch, process_full_tiles.py:327-345: model(np.array(batch), training=False)[..., -1] + 0.5."""
+    pred = np.array(model(np.array(batch), training=False))[:, :, :, -1] + 0.5
+    for p, k in zip(pred, index):
+        if k != (-1, -1):
+            out[k] = p
+
+
+def process_tile(img_p, dem_p, px: int, py: int, model: Callable, image_size: int, stride: int, batch_size: int,
+                 tile_size: int, no_value: float, as_implemented: bool = True, return_batches: bool = False):
+    """processTile, process_full_tiles.py:431-479 without the disk write.
+
+    Invalid patches are skipped; the final short batch is padded with float64 zero patches keyed
+    (-1, -1) (process_full_tiles.py:468-474) — they take part in the SPADE batch statistics.
+    """
+    generated: dict = {}
+    minmax: dict = {}
+    batch: list = []
+    index: list = []
+    calls = []
+    for xx, yy in patch_origins(px, py, tile_size, image_size, stride):
+        valid, ip, dp = get_patch(img_p, dem_p, xx, yy, image_size, no_value)
+        if not valid:
+            continue
+        patch, mm = normalize(ip, dp)
+        key = (xx - px, yy - py)
+        minmax[key] = mm
+        batch.append(patch)
+        index.append(key)
+        if len(batch) == batch_size:
+            calls.append(list(index))
+            run_batch(model, batch, index, generated)
+            batch, index = [], []
+    if batch:
+        while len(batch) < batch_size:
+            batch.append(np.zeros([image_size, image_size, 2]))
+            index.append((-1, -1))
+        calls.append(list(index))
+        run_batch(model, batch, index, generated)
+    result = rebuild_tile(generated, minmax, tile_size, image_size, stride, no_value, as_implemented)
+    if return_batches:
+        return result, calls
+    return result
+
+
+def process_map(img: np.ndarray, dem: np.ndarray, model: Callable = identity_model, image_size: int = 256,
+                stride: int = 32, batch_size: int = 16, tile_size: int = 1024, no_value: float = -32768.0,
+                as_implemented: bool = True):
+    """processMap minus file I/O and pre-processing: padInputs -> tiles -> rebuildMap
+    (process_full_tiles.py:568-587, 533-566).  Returns (mean, std, good) cropped to the input shape."""
+    img_p, dem_p = pad_inputs(img, dem, image_size, stride, no_value)
+    hp, wp = dem_p.shape
+    full = [np.zeros((hp, wp), np.float32), np.zeros((hp, wp), np.float32), np.zeros((hp, wp), np.uint8)]
+    for xx, yy in tile_list(dem.shape, tile_size):
+        parts = process_tile(img_p, dem_p, xx, yy, model, image_size, stride, batch_size, tile_size, no_value,
+                             as_implemented)
+        for canvas, part in zip(full, parts):
+            canvas[yy:yy + tile_size, xx:xx + tile_size] = part
+    h, w = dem.shape
+    return tuple(c[:h, :w] for c in full)
