@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the tiled DEM super-resolution hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload spade256|spade512]
+
+A "step" is one generator(call) — `self.model(np.array(batch), training=False)` of process_full_tiles.py:338 —
+over one batch of synthetic (ortho, low-res DEM) patches that is already resident in HBM:
+    spade256 (default, BASELINE.json configs[1]): GauGAN(256, 16, 256), batch [16,256,256,2] = 4 tiles of 512x512
+    spade512 (configs[2], the MFMA roofline run):  GauGAN(512,  8, 256), batch [ 8,512,512,2] = 8 tiles of 512x512
+Metric: 512x512 DEM tiles/s over the whole job (a 512x512 tile = four 256x256 patches).
+N > 1: one process per GPU (torch.distributed / RCCL only for the timing barrier + max); patches are
+independent units, so ranks share nothing on the data path ("weak" scaling: per-GPU work is fixed).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    "spade256": dict(S=256, B=16, name="SPADE-256 GauGAN(256,16,256) batch=16 256x256 patches (=4 512x512 tiles) per step"),
+    "spade512": dict(S=512, B=8, name="SPADE-512 GauGAN(512,8,256) batch=8 512x512 tiles per step"),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (matrix)": v_mfma_f32_32x32x2_f32, dense
+
+
+def cpu_baseline(S: int, sample_patches: int, weights, eps_full):
+    """Time the oracle (CPU restatement of the reference generator, PyTorch-CPU fp32) on a bounded sample."""
+    import numpy as np
+    import torch
+    from moonsuperresolution_amd import synthetic_patches
+    from oracle import generator_ref
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    wt = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in weights.items()}
+    x = synthetic_patches(sample_patches, S, seed=100)
+    t0 = time.perf_counter()
+    generator_ref.spade_call(x, wt, "gaugan", eps_full[:sample_patches], dtype=torch.float32)
+    dt = time.perf_counter() - t0
+    tiles = sample_patches * (S / 512.0) ** 2
+    return dict(value=tiles / dt, unit="512x512 tiles/s", cores=cores, kind="port",
+                sample=f"one oracle call (PyTorch-CPU fp32 restatement, not TensorFlow) on {sample_patches} "
+                       f"patches of {S}x{S} = {tiles:g} tiles, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="spade256")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from moonsuperresolution_amd import Generator, make_latent_noise, make_weights, synthetic_patches
+
+    wl = WORKLOADS[args.workload]
+    S, B = wl["S"], wl["B"]
+    weights = make_weights("gaugan", S, seed=1234)
+    eps = make_latent_noise(B, 256, seed=7)
+    gen = Generator(S, B, variant="gaugan", weights=weights, eps=eps, device=local)
+    # a small pool of distinct synthetic batches, resident in HBM before the timed region
+    pool = [torch.from_numpy(synthetic_patches(B, S, seed=1000 * rank + i)).cuda() for i in range(2)]
+    out = torch.empty((B, S, S, 1), dtype=torch.float32, device="cuda")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        gen.forward_device(pool[i % len(pool)], out=out)
+    barrier()
+    gen.profile(not args.no_profile)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        gen.forward_device(pool[i % len(pool)], out=out)
+        ev[i][1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    step_ms = [a.elapsed_time(b) for a, b in ev]
+    stats = gen.profile_read() if not args.no_profile else {}
+    gen.profile(False)
+    assert torch.isfinite(out).all(), "non-finite generator output"
+
+    tiles_per_step = B * (S / 512.0) ** 2
+    value = world * args.steps * tiles_per_step / elapsed
+    if rank == 0:
+        res = {
+            "metric": "512x512 DEM tiles/s (whole job)", "value": value, "unit": "tiles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl["name"], "image_size": S, "batch_size": B, "variant": "gaugan",
+                       "weights": "random-init (Keras default distributions), seed 1234",
+                       "tiles_per_step_per_gpu": tiles_per_step, "parallelism": f"tile-sharded x{world}"},
+            "patches_per_s": world * args.steps * B / elapsed,
+            "p50_latency_ms_per_tile": statistics.median(step_ms) / tiles_per_step,
+            "p50_ms_per_call": statistics.median(step_ms),
+            "forward_gflop_per_call": gen.forward_flops() / 1e9,
+            "achieved_tflops_whole_call": gen.forward_flops() * args.steps / elapsed / 1e12,
+            "device_mem_gib": gen.device_bytes() / 2 ** 30,
+        }
+        conv = stats.get("conv_igemm_f32")
+        if conv and conv["device_ms"] > 0:
+            ach = conv["flops"] / (conv["device_ms"] * 1e-3) / 1e12
+            res["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_f32", "achieved": ach,
+                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                               "traffic": None, "launches": conv["launches"],
+                               "avg_launch_ms": conv["device_ms"] / conv["launches"],
+                               "share_of_device_time": conv["device_ms"] / sum(v["device_ms"] for v in stats.values())}
+            res["kernel_ms_per_call"] = {k: v["device_ms"] / args.steps for k, v in stats.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(S, 4 if S == 256 else 1, weights, eps)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
