@@ -1,0 +1,267 @@
+"""Tiled inference driver on the GPU — the host-side mirror of ``DEMSuperResolution`` (process_full_tiles.py:129-587).
+
+Same names and argument meaning as the reference for the part of the class that is on the hot path
+(``DSRConfig``, ``padInputs``, ``generateTileList``, ``processTile``, ``rebuildTile``, ``rebuildMap``); raster file
+I/O and nodata in-filling (``loadImages``/``preprocess``/``saveGTiff``: GDAL, OpenCV, SciPy) are out of scope
+ — rasters come in as arrays through ``setImages``.
+
+What moves to the GPU (libmoonsr_hip.so, csrc/tiler.hip):
+  getPatch + normalize     -> msr_patch_stats + msr_extract_patches   (validity, min/max, [-0.5,0.5] scaling)
+  processBatch             -> Generator.forward_device (patches never leave HBM) or any host callable
+  rebuildTile              -> msr_stitch_tile (gather-form weighted incremental mean / variance, bit-exact)
+The only host synchronisation per tile is the read-back of the patch validity flags, which decide the batch
+composition exactly as the reference's Python loop does (invalid patches are skipped, the last batch is
+zero-padded: process_full_tiles.py:455-474) — SPADE's batch statistics make that composition part of the result.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+@dataclasses.dataclass
+class DSRConfig:
+    """process_full_tiles.py:53-66, field for field."""
+    image_size: int = 256
+    stride: int = 32
+    batch_size: int = 16
+    tile_size: int = 1024
+    no_value: float = -32768.0
+    upsample_factor: float = 1.0
+    map_name: str = None
+    save_path: str = None
+    source_folder_path: str = None
+    ortho_image_name: str = "run-DRG.tif"
+    dem_name: str = "run-DEM.tif"
+    model_path: str = None
+
+
+def blend_window(image_size: int) -> np.ndarray:
+    """makeGaussianKernel + 1e-7, purged S//16 per side (process_full_tiles.py:347-361, 391-393), float64.
+
+    Evaluated with NumPy exactly as the reference writes it so that the GPU stitcher, which takes this array,
+    is bit-identical to the NumPy path (libm's exp may differ from NumPy's in the last bit)."""
+    S = image_size
+
+    def gaus2d(x=0, y=0, mx=0, my=0, sx=1, sy=1):
+        return 1. / (2. * np.pi * sx * sy) * np.exp(-((x - mx) ** 2. / (2. * sx ** 2.) + (y - my) ** 2. / (2. * sy ** 2.)))
+    x = np.linspace(-S / 2, S / 2, S)
+    xg, yg = np.meshgrid(x, x)
+    kern = gaus2d(xg, yg, sx=S / 5, sy=S / 5)
+    kern = (kern - kern.min()) / (kern.max() - kern.min())
+    p = S // 16
+    return np.ascontiguousarray((kern + 1e-7)[p:-p, p:-p])
+
+
+class DEMSuperResolution:
+    """GPU tiler/stitcher with the reference's interface (process_full_tiles.py:129-156).
+
+    Args:
+        config: DSRConfig.
+        model: a ``moonsuperresolution_amd.Generator`` (device fast path) or any callable
+            ``model(batch[B,S,S,2], training=False) -> [B,S,S,C]`` like the reference accepts; the default is the
+            reference's identity self-check (process_full_tiles.py:143).
+        device: HIP device ordinal.
+        as_implemented: keep the reference's aliased variance update; False = textbook West.
+    """
+
+    def __init__(self, config: DSRConfig, model: Callable = lambda x, training=False: x, device: int = 0,
+                 as_implemented: bool = True) -> None:
+        self.map_name = config.map_name
+        self.save_path = config.save_path
+        self.folder_path = config.source_folder_path
+        self.no_value = float(config.no_value)
+        self.stride = int(config.stride)
+        self.image_size = int(config.image_size)
+        self.batch_size = int(config.batch_size)
+        self.upsample_factor = 1                     # process_full_tiles.py:153
+        self.tile_size = int(config.tile_size)
+        self.model = model
+        self.as_implemented = as_implemented
+        S, s = self.image_size, self.stride
+        if S < 64 or S & (S - 1):
+            raise ValueError("image_size must be a power of two >= 64")
+        if s <= 0 or s > S:
+            raise ValueError("stride must be in (0, image_size]")
+        if not torch.cuda.is_available():
+            raise RuntimeError("moonsuperresolution_amd needs a HIP device (MI355X / gfx950); there is no CPU fallback")
+        self.device = torch.device("cuda", device)
+        self._lib = _lib.load()
+        from .generator import Generator
+        self._gen: Optional[Generator] = model if isinstance(model, Generator) else None
+        if self._gen is not None:
+            if self._gen.image_size != S or self._gen.batch_size != self.batch_size:
+                raise ValueError("Generator image_size/batch_size differ from the DSRConfig")
+            self._h = self._gen._h
+            self._own_handle = False
+        else:
+            # a handle only for the tiler kernels (no weights needed); variant is irrelevant
+            cfg = _lib.MsrConfig(S, max(1, min(self.batch_size, 16)), 256, _lib.VARIANT_IDS["gaugan_no_kl"], device, 0)
+            h = C.c_void_p()
+            _lib.raise_for(self._lib, None, self._lib.msr_create(C.byref(cfg), C.byref(h)), "msr_create")
+            self._h = h
+            self._own_handle = True
+        w = blend_window(S)
+        rc = self._lib.msr_set_blend_window(self._h, w.ctypes.data_as(C.c_void_p), w.shape[0])
+        _lib.raise_for(self._lib, self._h, rc, "msr_set_blend_window")
+        self.dem = self.img = None
+        self.dem_padded = self.img_padded = None
+
+    # ------------------------------------------------------------------------------------------------
+    def setImages(self, img: np.ndarray, dem: np.ndarray) -> None:
+        """Stand-in for loadImages + preprocess (process_full_tiles.py:158-244): takes the arrays directly."""
+        img = np.asarray(img, np.float32)
+        dem = np.asarray(dem, np.float32)
+        if img.shape != dem.shape or img.ndim != 2:
+            raise ValueError("The ortho-image and the DEM must be 2-D arrays of the same shape.")
+        self.img, self.dem = img, dem
+        self.dem_shape = dem.shape
+        self.img_shape = img.shape
+
+    def padInputs(self) -> None:
+        """process_full_tiles.py:246-267: no_value canvas ((dim//1024)+1)*1024 + 2(S-s), data at offset (S-s)."""
+        S, s = self.image_size, self.stride
+        new_x = ((self.dem_shape[1] // 1024) + 1) * 1024 + (S - s) * 2
+        new_y = ((self.dem_shape[0] // 1024) + 1) * 1024 + (S - s) * 2
+        self.pad_x = new_x - self.dem_shape[1] - (S - s)
+        self.pad_y = new_y - self.dem_shape[0] - (S - s)
+        with torch.cuda.device(self.device):
+            self.dem_padded = torch.full((new_y, new_x), self.no_value, dtype=torch.float32, device=self.device)
+            self.img_padded = torch.full((new_y, new_x), self.no_value, dtype=torch.float32, device=self.device)
+            h, w = self.dem_shape
+            self.dem_padded[S - s:S - s + h, S - s:S - s + w] = torch.from_numpy(self.dem).to(self.device)
+            self.img_padded[S - s:S - s + h, S - s:S - s + w] = torch.from_numpy(self.img).to(self.device)
+        self.dem_padded_shape = tuple(self.dem_padded.shape)
+        self.img_padded_shape = tuple(self.img_padded.shape)
+        self.dem = None
+        self.img = None
+
+    def generateTileList(self) -> List[Tuple[int, int]]:
+        """process_full_tiles.py:313-325 — (xx, yy), y outer; the unit tiles are sharded by across GPUs."""
+        return [(xx, yy) for yy in range(0, self.dem_shape[0], self.tile_size)
+                for xx in range(0, self.dem_shape[1], self.tile_size)]
+
+    # ------------------------------------------------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def patchOrigins(self, px: int, py: int) -> np.ndarray:
+        """[n, 2] int32 (xx, yy) in padded coordinates, generation order (process_full_tiles.py:453-454)."""
+        span = self.tile_size + self.image_size - self.stride
+        ys = np.arange(py, py + span, self.stride, dtype=np.int32)
+        xs = np.arange(px, px + span, self.stride, dtype=np.int32)
+        return np.stack([np.tile(xs, len(ys)), np.repeat(ys, len(xs))], axis=1)
+
+    def processTile(self, px: int, py: int):
+        """process_full_tiles.py:431-479 without the disk write: returns (mean, std, good) device tensors [T,T].
+
+        Also records ``self.last_calls``: the patch keys of every generator call of the tile (with (-1,-1)
+        padding entries), i.e. the batch composition the reference would have produced."""
+        S, s, B, T = self.image_size, self.stride, self.batch_size, self.tile_size
+        lib, h, dev = self._lib, self._h, self.device
+        with torch.cuda.device(dev):
+            rows, cols = self.dem_padded_shape
+            org = self.patchOrigins(px, py)
+            n = org.shape[0]
+            ox = torch.from_numpy(np.ascontiguousarray(org[:, 0])).to(dev)
+            oy = torch.from_numpy(np.ascontiguousarray(org[:, 1])).to(dev)
+            valid = torch.empty(n, dtype=torch.uint8, device=dev)
+            minmax = torch.empty((n, 4), dtype=torch.float32, device=dev)
+            rc = lib.msr_patch_stats(h, self.img_padded.data_ptr(), self.dem_padded.data_ptr(), rows, cols,
+                                     ox.data_ptr(), oy.data_ptr(), n, self.no_value, valid.data_ptr(),
+                                     minmax.data_ptr(), self._stream())
+            _lib.raise_for(lib, h, rc, "msr_patch_stats")
+            keep = np.flatnonzero(valid.cpu().numpy())          # the one host sync of the tile
+            nv = int(keep.size)
+            ncall = (nv + B - 1) // B
+            total = ncall * B
+            # compacted origins in generation order, padded with (-1,-1) up to a whole number of calls
+            sel = np.full((total, 2), -1, np.int32)
+            sel[:nv] = org[keep]
+            keys = sel.copy()
+            keys[:nv, 0] -= px
+            keys[:nv, 1] -= py
+            self.last_calls = [[tuple(int(v) for v in k) for k in keys[c * B:(c + 1) * B]] for c in range(ncall)]
+            mm_sel = torch.zeros((total, 4), dtype=torch.float32, device=dev)
+            if nv:
+                mm_sel[:nv] = minmax[torch.from_numpy(keep).to(dev)]
+            sx = torch.from_numpy(np.ascontiguousarray(sel[:, 0])).to(dev)
+            sy = torch.from_numpy(np.ascontiguousarray(sel[:, 1])).to(dev)
+            preds = torch.empty((max(total, 1), S, S), dtype=torch.float32, device=dev)
+            batch = torch.empty((B, S, S, 2), dtype=torch.float32, device=dev)
+            for c in range(ncall):
+                rc = lib.msr_extract_patches(h, self.img_padded.data_ptr(), self.dem_padded.data_ptr(), rows, cols,
+                                             sx[c * B:].data_ptr(), sy[c * B:].data_ptr(), mm_sel[c * B:].data_ptr(),
+                                             B, batch.data_ptr(), self._stream())
+                _lib.raise_for(lib, h, rc, "msr_extract_patches")
+                if self._gen is not None:
+                    out = self._gen.forward_device(batch)                       # [B,S,S,1], stays in HBM
+                    preds[c * B:(c + 1) * B] = out[..., -1]
+                else:
+                    out = np.array(self.model(batch.cpu().numpy(), training=False))[:, :, :, -1]
+                    preds[c * B:(c + 1) * B] = torch.from_numpy(np.ascontiguousarray(out, dtype=np.float32)).to(dev)
+            key_d = torch.from_numpy(np.ascontiguousarray(keys[:nv])).to(dev) if nv else torch.zeros((1, 2), dtype=torch.int32, device=dev)
+            dmm = mm_sel[:max(nv, 1), 2:4].contiguous()
+            return self.rebuildTile(preds, key_d, dmm, nv)
+
+    def rebuildTile(self, preds: torch.Tensor, keys: torch.Tensor, dem_minmax: torch.Tensor, n: Optional[int] = None):
+        """process_full_tiles.py:363-414 on the GPU.  preds [n,S,S] raw generator outputs (the +0.5 of :340 is
+        applied inside), keys [n,2] int32 (x,y) relative to the tile, dem_minmax [n,2].  Generation order."""
+        T = self.tile_size
+        n = int(keys.shape[0]) if n is None else n
+        with torch.cuda.device(self.device):
+            mean = torch.empty((T, T), dtype=torch.float32, device=self.device)
+            std = torch.empty((T, T), dtype=torch.float32, device=self.device)
+            good = torch.empty((T, T), dtype=torch.uint8, device=self.device)
+            rc = self._lib.msr_stitch_tile(self._h, preds.data_ptr(), keys.data_ptr(), dem_minmax.data_ptr(), n, T,
+                                           self.stride, self.no_value, 1 if self.as_implemented else 0,
+                                           mean.data_ptr(), std.data_ptr(), good.data_ptr(), self._stream())
+            _lib.raise_for(self._lib, self._h, rc, "msr_stitch_tile")
+        return mean, std, good
+
+    # ------------------------------------------------------------------------------------------------
+    def processTiles(self, tiles: Sequence[Tuple[int, int]]):
+        """Process a list of tiles (this rank's shard); returns {(xx,yy): (mean, std, good)} of host arrays."""
+        out = {}
+        for xx, yy in tiles:
+            m, s, g = self.processTile(xx, yy)
+            out[(xx, yy)] = (m.cpu().numpy(), s.cpu().numpy(), g.cpu().numpy())
+        return out
+
+    def rebuildMap(self, tiles: dict):
+        """process_full_tiles.py:533-566 without file I/O: paste tiles, crop to the input extent."""
+        hp, wp = self.dem_padded_shape
+        T = self.tile_size
+        mean = np.zeros((hp, wp), np.float32)
+        std = np.zeros((hp, wp), np.float32)
+        good = np.zeros((hp, wp), np.uint8)
+        for (xx, yy), (m, s, g) in tiles.items():
+            mean[yy:yy + T, xx:xx + T] = m
+            std[yy:yy + T, xx:xx + T] = s
+            good[yy:yy + T, xx:xx + T] = g
+        h, w = self.dem_shape
+        return mean[:h, :w], std[:h, :w], good[:h, :w]
+
+    def processMap(self, img: Optional[np.ndarray] = None, dem: Optional[np.ndarray] = None):
+        """process_full_tiles.py:568-587 on arrays: pad, tile, generate, stitch, assemble."""
+        if img is not None:
+            self.setImages(img, dem)
+        self.padInputs()
+        return self.rebuildMap(self.processTiles(self.generateTileList()))
+
+    def close(self) -> None:
+        if getattr(self, "_own_handle", False) and self._h:
+            self._lib.msr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

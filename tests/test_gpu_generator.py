@@ -1,0 +1,162 @@
+"""GPU (-m gpu): the HIP generator(call) through the C ABI against the CPU oracle and the golden vectors.
+
+Tolerance: BASELINE.json north_star states <= 1e-3 relative L-infinity vs the reference generator output in fp32;
+every check here uses rel_linf = max|y - ref| / max|ref| against the float64 oracle and requires <= 1e-3
+(observed ~1e-5, the rounding of exact-fp32 MFMA accumulation)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from moonsuperresolution_amd import make_latent_noise, make_weights, synthetic_patches
+from tests.helpers import rel_linf
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def Generator(hip_lib):
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from moonsuperresolution_amd import Generator
+    return Generator
+
+
+@pytest.mark.parametrize("variant", ["gaugan", "gaugan_no_kl"])
+def test_spade64_matches_golden_and_blocks(Generator, variant):
+    g = np.load(os.path.join(GOLD, f"spade64_{variant}.npz"))
+    w = make_weights(variant, 64, seed=1234, bias_scale=0.05)
+    gen = Generator(64, 2, variant=variant, weights=w, eps=make_latent_noise(2, 256, 7))
+    y = gen(synthetic_patches(2, 64, 0), training=False)
+    assert y.shape == (2, 64, 64, 1) and y.dtype == np.float32
+    assert rel_linf(y, g["output"]) <= TOL
+    # per-block checksums of the fp64 oracle (mean |x| of every ResidualBlock output)
+    f = [1024, 1024, 1024, 512, 256, 128]
+    for i in range(1, 7):
+        r = 1 << (i - 1)
+        out = gen.debug_tensor(f"ws.gen.rb{i}.out", (2, r, r, f[i - 1]))
+        assert abs(np.abs(out).mean() / g[f"gen_rb{i}_out"] - 1) <= TOL, i
+    gen.close()
+
+
+def test_cnn_variant_equals_no_kl(Generator):
+    w = make_weights("cnn", 64, seed=1234, bias_scale=0.05)
+    x = synthetic_patches(2, 64, 0)
+    a = Generator(64, 2, variant="cnn", weights=w)(x)
+    b = Generator(64, 2, variant="gaugan_no_kl", weights=w)(x)
+    assert np.array_equal(a, b)
+    g = np.load(os.path.join(GOLD, "spade64_gaugan_no_kl.npz"))
+    assert rel_linf(a, g["output"]) <= TOL
+
+
+def test_zero_padding_patch_couples_through_batch_statistics(Generator):
+    """process_full_tiles.py:468-474 pads the last batch with zero patches; SPADE's batch moments (spade.py:21)
+    make the real patch's output depend on them — parity only holds per call with identical composition."""
+    g0 = np.load(os.path.join(GOLD, "spade64_gaugan.npz"))
+    gz = np.load(os.path.join(GOLD, "spade64_zero.npz"))
+    w = make_weights("gaugan", 64, seed=1234, bias_scale=0.05)
+    gen = Generator(64, 2, variant="gaugan", weights=w, eps=make_latent_noise(2, 256, 7))
+    x = synthetic_patches(2, 64, 0)
+    x[1] = 0.0
+    y = gen(x)
+    assert rel_linf(y, gz["output"]) <= TOL
+    assert rel_linf(y[0], g0["output"][0]) > 10 * TOL      # same patch 0, different batch mate -> different result
+    gen.close()
+
+
+def test_float64_batch_and_list_input_accepted(Generator):
+    """np.array(batch) is float64 when zero patches were appended (process_full_tiles.py:472): same result."""
+    w = make_weights("gaugan_no_kl", 64, seed=1234)
+    gen = Generator(64, 2, variant="gaugan_no_kl", weights=w)
+    x = synthetic_patches(2, 64, 1)
+    a = gen(x)
+    b = gen([x[0].astype(np.float64), x[1].astype(np.float64)], training=False)
+    assert np.array_equal(a, b)
+    assert np.array_equal(np.array(a)[:, :, :, -1], a[..., 0])     # what processBatch does with the result
+    gen.close()
+
+
+def test_error_behaviour(Generator):
+    w = make_weights("gaugan", 64, seed=1234)
+    gen = Generator(64, 2, variant="gaugan", weights=w, eps=7)
+    with pytest.raises(ValueError):
+        gen(np.zeros((3, 64, 64, 2), np.float32))           # batch != batch_size (sampling.py:13-15)
+    with pytest.raises(ValueError):
+        gen(np.zeros((2, 32, 32, 2), np.float32))
+    with pytest.raises(ValueError):
+        gen(np.zeros((2, 64, 64, 2), np.float32), training=True)
+    bad = dict(w)
+    bad.pop("gen.rb3.conv_2.kernel")
+    with pytest.raises(ValueError):
+        Generator(64, 2, variant="gaugan", weights=bad)
+    bad = dict(w)
+    bad["gen.head.kernel"] = np.zeros((3, 3, 128, 1), np.float32)
+    with pytest.raises(ValueError):
+        Generator(64, 2, variant="gaugan", weights=bad)
+    with pytest.raises(ValueError):
+        Generator(96, 2)
+    gen.close()
+
+
+def test_unseeded_sampler_draws_fresh_noise(Generator):
+    w = make_weights("gaugan", 64, seed=1234)
+    gen = Generator(64, 2, variant="gaugan", weights=w, eps=None)
+    x = synthetic_patches(2, 64, 2)
+    assert not np.array_equal(gen(x), gen(x))               # tf.random.normal is unseeded (sampling.py:13)
+    gen.close()
+
+
+def test_spade256_against_oracle(Generator):
+    """BASELINE config 2 geometry (S=256) at B=2 so the fp64 oracle finishes in seconds."""
+    from oracle import generator_ref
+    w = make_weights("gaugan", 256, seed=1234, bias_scale=0.05)
+    eps = make_latent_noise(2, 256, 7)
+    x = synthetic_patches(2, 256, 0)
+    gen = Generator(256, 2, variant="gaugan", weights=w, eps=eps)
+    y = gen(x)
+    cap = {}
+    ref = generator_ref.spade_call(x, w, "gaugan", eps, dtype=torch.float64, capture=cap)
+    assert rel_linf(y, ref) <= TOL
+    assert rel_linf(gen.last_latent(), cap["z"]) <= TOL
+    assert rel_linf(gen.debug_tensor("ws.gen.rb6.x1", (2, 128, 128, 128)), cap["gen.rb6.x1"]) <= TOL
+    assert abs(gen.forward_flops() / 2 / 1e9 - 175.652) < 1e-3
+    gen.close()
+
+
+def test_full_size_configs_properties(Generator):
+    """BASELINE configs 2 and 3 at full batch: size-independent properties (the oracle would take minutes)."""
+    for S, B in ((256, 16), (512, 8)):
+        gen = Generator(S, B, variant="gaugan", weights=1234, eps=7)
+        x = torch.from_numpy(synthetic_patches(B, S, 11)).cuda()
+        a = gen.forward_device(x).clone()
+        b = gen.forward_device(x).clone()
+        assert torch.equal(a, b)                               # deterministic: no atomics on the path
+        assert a.shape == (B, S, S, 1) and torch.isfinite(a).all()
+        # permuting the batch permutes the output (batch statistics are permutation invariant); the latent
+        # noise is per row, so permute it too
+        perm = torch.arange(B - 1, -1, -1)
+        eps = torch.from_numpy(make_latent_noise(B, 256, 7)).cuda()
+        c = gen.forward_device(x[perm].contiguous(), eps=eps[perm].contiguous())
+        err = float((c[perm] - a).abs().max() / a.abs().max())
+        assert err <= 1e-4, err
+        assert abs(gen.forward_flops() / B / 1e9 - (175.652 if S == 256 else 702.607)) < 1e-3
+        gen.close()
+        del gen
+        torch.cuda.empty_cache()
+
+
+def test_pix2pix_against_oracle(Generator):
+    from oracle import generator_ref
+    g = np.load(os.path.join(GOLD, "pix2pix256.npz"))
+    w = make_weights("pix2pix", 256, seed=1234, bias_scale=0.05)
+    x = synthetic_patches(1, 256, 3)
+    gen = Generator(256, 1, variant="pix2pix", weights=w)
+    y = gen(x)
+    ref = generator_ref.pix2pix_call(x, w, dtype=torch.float64)
+    assert y.shape == (1, 256, 256, 1) and np.abs(y).max() < 1.0
+    assert rel_linf(y, ref) <= TOL
+    assert np.allclose(y[0, 16::32, 16::32, 0], g["probe"], atol=TOL * g["absmax"])
+    assert abs(gen.forward_flops() / 1e9 - 11.929) < 1e-3
+    gen.close()

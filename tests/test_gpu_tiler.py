@@ -1,0 +1,156 @@
+"""GPU (-m gpu): tiler / stitcher kernels through the C ABI, bit-exact against the NumPy oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tiler_ref
+from tests.helpers import rel_linf, stitch_inputs, synthetic_raster
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+NOVAL = -32768.0
+
+
+def f32_identity(x, training=False):
+    """The reference's identity self-check, returning float32 like a real model does."""
+    return np.asarray(x, np.float32)
+
+
+@pytest.fixture(scope="module")
+def dsr(hip_lib):
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from moonsuperresolution_amd import DEMSuperResolution, DSRConfig
+    return DEMSuperResolution, DSRConfig
+
+
+def test_stitch_bit_exact_vs_golden_and_oracle(dsr):
+    DEMSuperResolution, DSRConfig = dsr
+    g = np.load(os.path.join(GOLD, "stitch_small.npz"))
+    keys, pred, mm = stitch_inputs()
+    for as_impl, km, ks in ((True, "mean", "std"), (False, "mean_textbook", "std_textbook")):
+        d = DEMSuperResolution(DSRConfig(image_size=64, stride=16, batch_size=4, tile_size=128), as_implemented=as_impl)
+        mean, std, good = d.rebuildTile(torch.from_numpy(pred).cuda(), torch.from_numpy(keys).cuda(),
+                                        torch.from_numpy(mm).cuda())
+        assert np.array_equal(mean.cpu().numpy(), g[km])          # bit-exact, float32
+        assert np.array_equal(std.cpu().numpy(), g[ks])
+        assert np.array_equal(good.cpu().numpy(), g["good"])
+        d.close()
+
+
+def test_patch_stats_and_extract_bit_exact(dsr):
+    DEMSuperResolution, DSRConfig = dsr
+    img, dem = synthetic_raster(300, 420, 7, hole=(100, 140, 200, 260))
+    d = DEMSuperResolution(DSRConfig(image_size=64, stride=16, batch_size=4, tile_size=128))
+    d.setImages(img, dem)
+    d.padInputs()
+    img_p, dem_p = tiler_ref.pad_inputs(img, dem, 64, 16, NOVAL)
+    assert np.array_equal(d.img_padded.cpu().numpy(), img_p) and np.array_equal(d.dem_padded.cpu().numpy(), dem_p)
+    assert d.generateTileList() == tiler_ref.tile_list(dem.shape, 128)
+    org = d.patchOrigins(128, 0)
+    assert [tuple(o) for o in org] == tiler_ref.patch_origins(128, 0, 128, 64, 16)
+    # run the kernels directly on every origin of the tile
+    import ctypes as C
+    from moonsuperresolution_amd import _lib
+    n = len(org)
+    ox = torch.from_numpy(np.ascontiguousarray(org[:, 0])).cuda()
+    oy = torch.from_numpy(np.ascontiguousarray(org[:, 1])).cuda()
+    valid = torch.empty(n, dtype=torch.uint8, device="cuda")
+    mm = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    rows, cols = d.dem_padded_shape
+    rc = d._lib.msr_patch_stats(d._h, d.img_padded.data_ptr(), d.dem_padded.data_ptr(), rows, cols, ox.data_ptr(),
+                                oy.data_ptr(), n, NOVAL, valid.data_ptr(), mm.data_ptr(), None)
+    assert rc == 0
+    out = torch.empty((n, 64, 64, 2), dtype=torch.float32, device="cuda")
+    rc = d._lib.msr_extract_patches(d._h, d.img_padded.data_ptr(), d.dem_padded.data_ptr(), rows, cols,
+                                    ox.data_ptr(), oy.data_ptr(), mm.data_ptr(), n, out.data_ptr(), None)
+    assert rc == 0
+    valid, mm, out = valid.cpu().numpy(), mm.cpu().numpy(), out.cpu().numpy()
+    nvalid = 0
+    for i, (xx, yy) in enumerate(org):
+        ok, ip, dp = tiler_ref.get_patch(img_p, dem_p, int(xx), int(yy), 64, NOVAL)
+        assert bool(valid[i]) == ok
+        if ok:
+            nvalid += 1
+            patch, (lo, hi) = tiler_ref.normalize(ip, dp)
+            assert mm[i, 2] == lo and mm[i, 3] == hi and mm[i, 0] == ip.min() and mm[i, 1] == ip.max()
+            assert np.array_equal(out[i], patch)                   # bit-exact float32 normalisation
+    assert 0 < nvalid < n
+    d.close()
+
+
+def test_identity_model_map_bit_exact(dsr):
+    """The reference's own known-answer check (process_full_tiles.py:139-143) end to end on the GPU tiler,
+    against the NumPy oracle driven by the same (float32) identity model: every output bit-identical."""
+    DEMSuperResolution, DSRConfig = dsr
+    img, dem = synthetic_raster(200, 330, 3, hole=(90, 110, 140, 170))
+    cfg = DSRConfig(image_size=64, stride=16, batch_size=4, tile_size=128)
+    d = DEMSuperResolution(cfg, model=f32_identity)
+    mean, std, good = d.processMap(img, dem)
+    rm, rs, rg = tiler_ref.process_map(img, dem, f32_identity, 64, 16, 4, 128, NOVAL)
+    assert np.array_equal(good, rg) and np.array_equal(mean, rm) and np.array_equal(std, rs)
+    ok = good == 1
+    assert np.abs(mean[ok] - dem[ok]).max() < 2e-3 * (dem[ok].max() - dem[ok].min()) and std[ok].max() < 0.05
+    # the reference's literal identity lambda returns float64 for the zero-padded last batch: last-bit effects only
+    rm64, _, rg64 = tiler_ref.process_map(img, dem, tiler_ref.identity_model, 64, 16, 4, 128, NOVAL)
+    assert np.array_equal(rg64, good) and rel_linf(mean[ok], rm64[ok]) < 1e-6
+    d.close()
+
+
+def test_batch_composition_matches_reference(dsr):
+    DEMSuperResolution, DSRConfig = dsr
+    img, dem = synthetic_raster(100, 100, 4, hole=(0, 30, 0, 30))
+    d = DEMSuperResolution(DSRConfig(image_size=64, stride=32, batch_size=4, tile_size=128), model=f32_identity)
+    d.setImages(img, dem)
+    d.padInputs()
+    d.processTile(0, 0)
+    img_p, dem_p = tiler_ref.pad_inputs(img, dem, 64, 32, NOVAL)
+    _, calls = tiler_ref.process_tile(img_p, dem_p, 0, 0, f32_identity, 64, 32, 4, 128, NOVAL, return_batches=True)
+    assert d.last_calls == calls
+    d.close()
+
+
+def test_generator_through_tiler_vs_oracle(dsr):
+    """process_full_tiles over the HIP generator vs the oracle tiler over the oracle generator, same weights,
+    same batch composition (gaugan_no_kl: no sampler noise)."""
+    from moonsuperresolution_amd import Generator, make_weights
+    from oracle import generator_ref
+    DEMSuperResolution, DSRConfig = dsr
+    w = make_weights("gaugan_no_kl", 64, seed=1234, bias_scale=0.05)
+    img, dem = synthetic_raster(120, 120, 9)
+    cfg = DSRConfig(image_size=64, stride=32, batch_size=4, tile_size=128)
+    gen = Generator(64, 4, variant="gaugan_no_kl", weights=w)
+    d = DEMSuperResolution(cfg, model=gen)
+    mean, std, good = d.processMap(img, dem)
+    wt = {k: torch.from_numpy(v) for k, v in w.items()}
+    rm, rs, rg = tiler_ref.process_map(
+        img, dem, lambda x, training=False: generator_ref.spade_call(x, wt, "gaugan_no_kl", dtype=torch.float32),
+        64, 32, 4, 128, NOVAL)
+    assert np.array_equal(good, rg) and good.any()
+    ok = good == 1
+    span = float(dem.max() - dem.min())
+    assert np.abs(mean[ok] - rm[ok]).max() <= 1e-3 * span
+    assert np.abs(std[ok] - rs[ok]).max() <= 1e-3 * span
+    d.close()
+    gen.close()
+
+
+def test_full_size_stitch_properties(dsr):
+    """BASELINE geometry S=512, s=64, T=1024 (529 patches): constant predictions stitch to a constant."""
+    DEMSuperResolution, DSRConfig = dsr
+    S, s, T = 512, 64, 1024
+    d = DEMSuperResolution(DSRConfig(image_size=S, stride=s, batch_size=8, tile_size=T))
+    n_side = len(range(0, T + S - s, s))
+    keys = np.array([(ix * s, iy * s) for iy in range(n_side) for ix in range(n_side)], np.int32)
+    n = len(keys)
+    assert n == 529
+    pred = torch.full((n, S, S), 0.25, dtype=torch.float32, device="cuda")      # -> 0.75 after +0.5
+    mm = torch.tensor([[-100.0, 100.0]] * n, dtype=torch.float32, device="cuda")
+    mean, std, good = d.rebuildTile(pred, torch.from_numpy(keys).cuda(), mm)
+    assert good.all() and torch.all(mean == 50.0) and float(std.max()) < 1e-4
+    # dropping every patch of the first two patch rows leaves the top strip un-reconstructed
+    keep = keys[:, 1] >= 2 * s
+    mean2, std2, good2 = d.rebuildTile(pred[: int(keep.sum())], torch.from_numpy(keys[keep]).cuda(), mm[: int(keep.sum())])
+    assert good2[100:].all() and torch.all(mean2[good2.bool()] == 50.0)
+    d.close()
