@@ -38,7 +38,7 @@ struct TileGeom {
 };
 
 template <int WM, int WN, int MT, int NT, int EPI>
-__global__ void __launch_bounds__(WM * WN * 64, 2)
+__global__ void __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv_igemm_f32(const ConvParams p, const TileGeom g) {
     constexpr int NTHR = WM * WN * 64;
     constexpr int BM = WM * MT * 32;
@@ -109,63 +109,121 @@ conv_igemm_f32(const ConvParams p, const TileGeom g) {
     const int taps = p.KH * p.KW;
     const int chunks = p.Cin / BKC;
     const int steps = taps * chunks;
-    const int w_tap_stride = p.N * p.Cin;
+    const size_t w_tap_stride = (size_t)p.N * p.Cin;
 
-    float4 ra[A_ITEMS], rb[B_ITEMS];
-    auto issue_loads = [&](int t) {
-        const int cc = t / taps, tap = t - cc * taps;
-        const int kh = tap / p.KW, kw = tap - kh * p.KW;
-        const float* ain = p.in + (kh * p.in_py + kw * p.Cin + cc * BKC);
-        const float* win = p.wt + ((size_t)tap * w_tap_stride + cc * BKC);
-#pragma unroll
-        for (int q = 0; q < A_ITEMS; ++q) ra[q] = *reinterpret_cast<const float4*>(ain + a_goff[q]);
-#pragma unroll
-        for (int q = 0; q < B_ITEMS; ++q) rb[q] = *reinterpret_cast<const float4*>(win + b_goff[q]);
-    };
-    auto write_lds = [&](int buf) {
-        float* a = As + buf * BM * BKP;
-        float* b = Bs + buf * BN * BKP;
-#pragma unroll
-        for (int q = 0; q < A_ITEMS; ++q) *reinterpret_cast<float4*>(a + a_loff[q]) = ra[q];
-#pragma unroll
-        for (int q = 0; q < B_ITEMS; ++q) *reinterpret_cast<float4*>(b + b_loff[q]) = rb[q];
-    };
+    // K-step iterator: channel chunk outer, tap inner (kh, kw), kept as running scalars (no divisions).
+    int it_kh = 0, it_kw = 0;
+    const float* a_src = p.in;               // + kh*in_py + kw*Cin + cc*BKC
+    const float* b_src = p.wt;               // + tap*N*Cin + cc*BKC
 
-    issue_loads(0);
-    write_lds(0);
-    __syncthreads();
-
-    for (int t = 0; t < steps; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < steps) issue_loads(t + 1);
-        const float* a = As + cur * BM * BKP;
-        const float* b = Bs + cur * BN * BKP;
-#pragma unroll
-        for (int kk = 0; kk < BKC / 8; ++kk) {
-            float4 fa[MT], fb[NT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) fa[m] = *reinterpret_cast<const float4*>(a + a_frag[m] + kk * 8);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) fb[n] = *reinterpret_cast<const float4*>(b + b_frag[n] + kk * 8);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const float av = s == 0 ? fa[m].x : s == 1 ? fa[m].y : s == 2 ? fa[m].z : fa[m].w;
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        const float bv = s == 0 ? fb[n].x : s == 1 ? fb[n].y : s == 2 ? fb[n].z : fb[n].w;
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m][n], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        if (t + 1 < steps) write_lds(cur ^ 1);
-        __syncthreads();
+    // Staging registers.  Everything below is written so that ra/rb stay in VGPRs: fixed trip counts,
+    // compile-time indices, and no conditional around the load/write pair (the last K-step is peeled).
+    // Named scalars, not arrays: hipcc leaves a float4 array that crosses a sched_barrier in scratch memory.
+    static_assert(A_ITEMS == 4 && B_ITEMS == 4, "staging is written for 4 + 4 16-byte items per thread");
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define MSR_ISSUE_LOADS()                                                                        \
+    {                                                                                            \
+        ra0 = *reinterpret_cast<const float4*>(a_src + a_goff[0]);                               \
+        ra1 = *reinterpret_cast<const float4*>(a_src + a_goff[1]);                               \
+        ra2 = *reinterpret_cast<const float4*>(a_src + a_goff[2]);                               \
+        ra3 = *reinterpret_cast<const float4*>(a_src + a_goff[3]);                               \
+        rb0 = *reinterpret_cast<const float4*>(b_src + b_goff[0]);                               \
+        rb1 = *reinterpret_cast<const float4*>(b_src + b_goff[1]);                               \
+        rb2 = *reinterpret_cast<const float4*>(b_src + b_goff[2]);                               \
+        rb3 = *reinterpret_cast<const float4*>(b_src + b_goff[3]);                               \
     }
+#define MSR_ADVANCE()                                                                            \
+    {                                                                                            \
+        ++it_kw;                                                                                 \
+        a_src += p.Cin;                                                                          \
+        b_src += w_tap_stride;                                                                   \
+        if (it_kw == p.KW) {                                                                     \
+            it_kw = 0;                                                                           \
+            ++it_kh;                                                                             \
+            a_src += p.in_py - p.KW * p.Cin;                                                     \
+            if (it_kh == p.KH) {                                                                 \
+                it_kh = 0;                                                                       \
+                a_src += BKC - p.KH * p.in_py;                                                   \
+                b_src += BKC - (size_t)taps * w_tap_stride;                                      \
+            }                                                                                    \
+        }                                                                                        \
+    }
+#define MSR_WRITE_LDS(buf)                                                                       \
+    {                                                                                            \
+        float* a_ = As + (buf) * BM * BKP;                                                       \
+        float* b_ = Bs + (buf) * BN * BKP;                                                       \
+        *reinterpret_cast<float4*>(a_ + a_loff[0]) = ra0;                                        \
+        *reinterpret_cast<float4*>(a_ + a_loff[1]) = ra1;                                        \
+        *reinterpret_cast<float4*>(a_ + a_loff[2]) = ra2;                                        \
+        *reinterpret_cast<float4*>(a_ + a_loff[3]) = ra3;                                        \
+        *reinterpret_cast<float4*>(b_ + b_loff[0]) = rb0;                                        \
+        *reinterpret_cast<float4*>(b_ + b_loff[1]) = rb1;                                        \
+        *reinterpret_cast<float4*>(b_ + b_loff[2]) = rb2;                                        \
+        *reinterpret_cast<float4*>(b_ + b_loff[3]) = rb3;                                        \
+    }
+#define MSR_COMPUTE(buf)                                                                         \
+    {                                                                                            \
+        const float* a_ = As + (buf) * BM * BKP;                                                 \
+        const float* b_ = Bs + (buf) * BN * BKP;                                                 \
+        _Pragma("unroll") for (int kk = 0; kk < BKC / 8; ++kk) {                                 \
+            float4 fa[MT], fb[NT];                                                               \
+            _Pragma("unroll") for (int m = 0; m < MT; ++m)                                       \
+                fa[m] = *reinterpret_cast<const float4*>(a_ + a_frag[m] + kk * 8);               \
+            _Pragma("unroll") for (int n = 0; n < NT; ++n)                                       \
+                fb[n] = *reinterpret_cast<const float4*>(b_ + b_frag[n] + kk * 8);               \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                      \
+                _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                 \
+                    const float av = s == 0 ? fa[m].x : s == 1 ? fa[m].y : s == 2 ? fa[m].z : fa[m].w; \
+                    _Pragma("unroll") for (int n = 0; n < NT; ++n) {                             \
+                        const float bv = s == 0 ? fb[n].x : s == 1 ? fb[n].y : s == 2 ? fb[n].z : fb[n].w; \
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m][n], 0, 0, 0); \
+                    }                                                                            \
+                }                                                                                \
+            }                                                                                    \
+        }                                                                                        \
+    }
+
+    MSR_ISSUE_LOADS();
+    MSR_WRITE_LDS(0);
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < steps - 1; ++t) {
+        MSR_ADVANCE();
+        MSR_ISSUE_LOADS();       // global loads of step t+1 fly while the MFMAs of step t run
+        __builtin_amdgcn_sched_barrier(0);   // keep hipcc from sinking the loads below the MFMAs
+        MSR_COMPUTE(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        MSR_WRITE_LDS(cur ^ 1);  // the other buffer was last read before the previous barrier
+        __syncthreads();
+        cur ^= 1;
+    }
+    MSR_COMPUTE(cur);
+#undef MSR_ISSUE_LOADS
+#undef MSR_ADVANCE
+#undef MSR_WRITE_LDS
+#undef MSR_COMPUTE
 
     // ---- epilogue -----------------------------------------------------------------------------------
     // C/D map of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
+    // Per-column constants (bias, SPADE mean / std) are loaded once, before the row loops.
+    constexpr int NCH = EPI == EPI_SPADE ? NT / 2 : NT;
+    float cb0[NCH], cb1[NCH], cmean[NCH], cstd[NCH];
+    int ccol[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        if constexpr (EPI == EPI_SPADE) {
+            const int colg = n0 + (wn * NT + 2 * j) * 32 + l31;   // gamma column; its beta twin is +32
+            ccol[j] = (n0 + wn * NT * 32) / 2 + j * 32 + l31;    // channel
+            cb0[j] = p.bias[colg];
+            cb1[j] = p.bias[colg + 32];
+            cmean[j] = p.mean[ccol[j]];
+            cstd[j] = p.stdv[ccol[j]];
+        } else {
+            ccol[j] = n0 + (wn * NT + j) * 32 + l31;
+            cb0[j] = p.bias[ccol[j]];
+            cb1[j] = cmean[j] = cstd[j] = 0.f;
+        }
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -180,15 +238,13 @@ conv_igemm_f32(const ConvParams p, const TileGeom g) {
                 const float* xrow = p.aux + (size_t)bb * p.aux_pb + (y >> p.aux_shift) * p.aux_py +
                                     (x >> p.aux_shift) * p.aux_px;
 #pragma unroll
-                for (int j = 0; j < NT / 2; ++j) {
-                    const int colg = n0 + (wn * NT + 2 * j) * 32 + l31;   // gamma column; beta is +32
-                    const int c = (n0 + wn * NT * 32) / 2 + j * 32 + l31;
-                    const float gam = acc[m][2 * j][r] + p.bias[colg];
-                    const float bet = acc[m][2 * j + 1][r] + p.bias[colg + 32];
-                    const float normalized = (xrow[c] - p.mean[c]) / p.stdv[c];
+                for (int j = 0; j < NCH; ++j) {
+                    const float gam = acc[m][2 * j][r] + cb0[j];
+                    const float bet = acc[m][2 * j + 1][r] + cb1[j];
+                    const float normalized = (xrow[ccol[j]] - cmean[j]) / cstd[j];
                     float v = gam * normalized + bet;
                     v = v >= 0.f ? v : v * p.slope;
-                    orow[c] = v;
+                    orow[ccol[j]] = v;
                 }
             } else {
                 const float* rrow = nullptr;
@@ -197,10 +253,9 @@ conv_igemm_f32(const ConvParams p, const TileGeom g) {
                            (x >> p.aux_shift) * p.aux_px;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    const int col = n0 + (wn * NT + n) * 32 + l31;
-                    float v = acc[m][n][r] + p.bias[col];
-                    if constexpr (EPI == EPI_RES) v += rrow[col];
-                    orow[col] = v;
+                    float v = acc[m][n][r] + cb0[n];
+                    if constexpr (EPI == EPI_RES) v += rrow[ccol[n]];
+                    orow[ccol[n]] = v;
                 }
             }
         }
