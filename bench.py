@@ -30,16 +30,45 @@ WORKLOADS = {
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (matrix)": v_mfma_f32_32x32x2_f32, dense
 
 
+def host_threads() -> int:
+    """Threads for the CPU baseline: the affinity mask, capped by the cgroup CPU quota and by the GPU box's
+    per-GPU CPU share (16; override with MSR_CPU_THREADS) — oversubscribing the share only slows the oracle."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("MSR_CPU_THREADS", "16"))))
+
+
+def pmc_traffic(workload: str):
+    """HBM bytes per conv_igemm_f32 launch from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json,
+    produced by profiles/summarize_pmc.py: separate FETCH_SIZE / WRITE_SIZE passes, KiB units, FETCH doubled on
+    gfx950 as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside this process."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("workload") == workload:
+            best = (d, os.path.basename(f))
+    return best
+
+
 def cpu_baseline(S: int, sample_patches: int, weights, eps_full):
     """Time the oracle (CPU restatement of the reference generator, PyTorch-CPU fp32) on a bounded sample."""
     import numpy as np
     import torch
     from moonsuperresolution_amd import synthetic_patches
     from oracle import generator_ref
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = host_threads()
     torch.set_num_threads(cores)
     wt = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in weights.items()}
     x = synthetic_patches(sample_patches, S, seed=100)
@@ -139,9 +168,15 @@ def main():
             ach = conv["flops"] / (conv["device_ms"] * 1e-3) / 1e12
             res["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_f32", "achieved": ach,
                                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                               "traffic": None, "launches": conv["launches"],
+                               "traffic": None, "traffic_unit": "bytes per launch (HBM, PMC)",
+                               "launches": conv["launches"],
                                "avg_launch_ms": conv["device_ms"] / conv["launches"],
                                "share_of_device_time": conv["device_ms"] / sum(v["device_ms"] for v in stats.values())}
+            res["roofline"]["algorithmic_flops_per_launch"] = conv["flops"] / conv["launches"]
+            pmc = pmc_traffic(args.workload)
+            if pmc:
+                res["roofline"]["traffic"] = pmc[0]["conv_igemm_f32"]["hbm_bytes_per_launch"]
+                res["roofline"]["traffic_source"] = "profiles/" + pmc[1]
             res["kernel_ms_per_call"] = {k: v["device_ms"] / args.steps for k, v in stats.items()}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(S, 4 if S == 256 else 1, weights, eps)

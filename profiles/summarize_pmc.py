@@ -1,0 +1,44 @@
+"""Summarise rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, collected in SEPARATE runs) into HBM bytes per
+launch per kernel family.  Units and corrections follow MI355X_MICROARCH.md "HBM": both counters are in KiB;
+on gfx950 FETCH_SIZE reports exactly half of a wide coalesced read stream, so it is doubled; WRITE_SIZE is exact.
+
+usage: python profiles/summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <workload> <out.json>
+"""
+import collections
+import csv
+import json
+import sys
+
+
+def family(name: str) -> str:
+    name = name.split("(")[0]
+    if "conv_igemm_f32" in name:
+        return "conv_igemm_f32"
+    return name.replace("void ", "").replace("msr::", "").split("<")[0]
+
+
+def collect(path, counter):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        f = family(r["Kernel_Name"])
+        agg[f][0] += 1
+        agg[f][1] += float(r["Counter_Value"])
+    return agg
+
+
+if __name__ == "__main__":
+    fetch, write, workload, out = sys.argv[1:5]
+    fa, wa = collect(fetch, "FETCH_SIZE"), collect(write, "WRITE_SIZE")
+    res = {"workload": workload, "note": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch (gfx950 FETCH correction)"}
+    for fam in sorted(set(fa) | set(wa)):
+        if not fam.startswith(("conv", "moments", "head", "dense", "norm", "latent")):
+            continue
+        n = max(fa[fam][0], wa[fam][0])
+        rd = 2.0 * fa[fam][1] * 1024 / max(fa[fam][0], 1)
+        wr = wa[fam][1] * 1024 / max(wa[fam][0], 1)
+        res[fam] = {"launches": n, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
+                    "hbm_bytes_per_launch": rd + wr}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
