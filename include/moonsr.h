@@ -130,6 +130,17 @@ int msr_profile_reset(msr_handle* h);
 int msr_profile_read(msr_handle* h, msr_kernel_stat* out, int32_t cap, int32_t* n);
 /* Algorithmic FLOPs of one msr_forward call (all patches), the figure BASELINE.md section 2 derives. */
 int msr_forward_flops(const msr_handle* h, double* flops);
+/* Kernel-level entry (parity tests and micro-benchmarks of the dominant kernel): one conv_igemm_f32 launch.
+ *   in_dev   zero-bordered NHWC input [B, rin+2, rin+2, Cin], rin = rout*stride
+ *   wt_dev   weights already in the kernel layout [9][N][Cin]; bias_dev [N] (GEMM column order)
+ *   epilogue 0 bias, 1 bias+residual(aux [B, rout>>aux_shift, ., N]), 2 SPADE (N = 2C, interleaved columns;
+ *            aux = x [B, rout>>aux_shift, ., C], mean/std [C]); out_padded != 0 writes a zero-bordered tensor
+ *   tile     -1 auto (tile and K split chosen by the library), else (0 = 128x128 | 1 = 64x64) + 256 * ksplit */
+int msr_op_conv3x3(msr_handle* h, const float* in_dev, const float* wt_dev, const float* bias_dev, float* out_dev,
+                   int32_t B, int32_t rout, int32_t Cin, int32_t N, int32_t stride, int32_t epilogue,
+                   const float* aux_dev, int32_t aux_shift, const float* mean_dev, const float* std_dev,
+                   int32_t out_padded, int32_t tile, void* stream);
+
 /* Debug / per-block parity aid: copy a named workspace tensor of the last msr_forward to a HOST buffer
  * (names: "ws.gen.x0", "ws.gen.rb3.x1", "ws.gen.rb3.out", "ws.enc.mv", ...).  Synchronises the device. */
 int msr_debug_tensor(msr_handle* h, const char* name, float* host_out, int64_t count);

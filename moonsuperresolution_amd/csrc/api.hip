@@ -65,6 +65,8 @@ struct msr_handle {
     double fwd_flops = 0;
     double* mom_partial = nullptr;
     float* dense_partial = nullptr;
+    float* conv_partial = nullptr;     // split-K workspace [ksplit][M][N]
+    size_t conv_partial_floats = 0;
     float* z = nullptr;
     // tiler
     double* window = nullptr;     // [S-2p, S-2p] float64
@@ -277,6 +279,7 @@ int msr_destroy(msr_handle* h) {
     for (auto& kv : h->dev) hipFree(kv.second);
     if (h->mom_partial) hipFree(h->mom_partial);
     if (h->dense_partial) hipFree(h->dense_partial);
+    if (h->conv_partial) hipFree(h->conv_partial);
     if (h->window) hipFree(h->window);
     if (h->stitch_grid) hipFree(h->stitch_grid);
     for (auto e : h->ev_pool) hipEventDestroy(e);
@@ -443,18 +446,20 @@ Op conv_op(const Padded& in, const float* wt, const float* bias, int B, int rout
     c.KH = 3; c.KW = 3; c.stride = stride;
     c.in_py = in.py(); c.in_pb = in.pb();
     c.slope = 0.2f;
-    op.tile = conv_pick_tile(B * rout * rout, N);
+    op.tile = conv_pick_tile(B * rout * rout, N, epi);
+    c.ksplit = conv_pick_ksplit(B * rout * rout, N, 9 * (in.C / 32), op.tile);
+    c.partial = nullptr;   // bound to the handle's workspace at launch
     op.flops = 2.0 * B * rout * rout * (double)in.C * N * 9;
     return op;
 }
 
-void out_dense(ConvParams& c, float* out, int r, int C) {
+void set_out_dense(ConvParams& c, float* out, int r, int C) {
     c.out = out; c.out_px = C; c.out_py = r * C; c.out_pb = r * r * C; c.out_off = 0;
 }
-void out_padded(ConvParams& c, const Padded& p) {
+void set_out_padded(ConvParams& c, const Padded& p) {
     c.out = p.base; c.out_px = p.C; c.out_py = p.py(); c.out_pb = p.pb(); c.out_off = p.interior();
 }
-void aux_dense(ConvParams& c, const float* x, int rx, int C, int shift) {
+void set_aux_dense(ConvParams& c, const float* x, int rx, int C, int shift) {
     c.aux = x; c.aux_px = C; c.aux_py = rx * C; c.aux_pb = rx * rx * C; c.aux_shift = shift;
 }
 
@@ -498,7 +503,7 @@ int plan_spade(msr_handle* h) {
         float* zero_bias; rc = dev_alloc(h, "ws.zero_bias", 2048, true, &zero_bias); if (rc) return rc;
         snprintf(n, sizeof n, "enc.ds%d.kernel", i);
         Op cv = conv_op(e_in, need(n), zero_bias, B, r, c, 2, EPI_BIAS);
-        out_dense(cv.conv, raw, r, c);
+        set_out_dense(cv.conv, raw, r, c);
         h->ops.push_back(cv);
         h->ops.push_back(moments_op(raw, B, r * r, c, 1e-3f, mean, stdv));
         mom_need(B, r * r, c);
@@ -523,7 +528,7 @@ int plan_spade(msr_handle* h) {
     const int K = rlast * rlast * 512;
     float* mv; rc = dev_alloc(h, "ws.enc.mv", (size_t)B * 2 * L, false, &mv); if (rc) return rc;
     rc = dev_alloc(h, "ws.z", (size_t)B * L, false, &h->z); if (rc) return rc;
-    size_t dense_part = (size_t)dense_splits(K) * B * 2 * L;
+    size_t dense_part = dense_partial_floats(B, K, 2 * L);
     {
         Op op; op.type = OP_DENSE;
         op.dense = {flat, need("enc.heads.kernel"), need("enc.heads.bias"), mv, B, K, 2 * L};
@@ -537,7 +542,7 @@ int plan_spade(msr_handle* h) {
     const int sw = S / 64;
     const int N0 = sw * sw * 1024;
     float* x_prev; rc = dev_alloc(h, "ws.gen.x0", (size_t)B * N0, false, &x_prev); if (rc) return rc;
-    dense_part = std::max(dense_part, (size_t)dense_splits(L) * B * N0);
+    dense_part = std::max(dense_part, dense_partial_floats(B, L, N0));
     {
         Op op; op.type = OP_DENSE;
         op.dense = {h->z, need("gen.dense.kernel"), need("gen.dense.bias"), x_prev, B, L, N0};
@@ -586,15 +591,15 @@ int plan_spade(msr_handle* h) {
             snprintf(k, sizeof k, "gen.rb%d.spade_%d.gb.kernel", i, j); const float* gbw = need(k);
             snprintf(k, sizeof k, "gen.rb%d.spade_%d.gb.bias", i, j); const float* gbb = need(k);
             Op gb = conv_op(hb, gbw, gbb, B, r, 2 * C, 1, EPI_SPADE);
-            out_padded(gb.conv, ab);
-            aux_dense(gb.conv, x, rx, C, xshift);
+            set_out_padded(gb.conv, ab);
+            set_aux_dense(gb.conv, x, rx, C, xshift);
             gb.conv.mean = mean; gb.conv.stdv = stdv;
             h->ops.push_back(gb);
             snprintf(k, sizeof k, "gen.rb%d.conv_%d.kernel", i, conv_idx); const float* cw = need(k);
             snprintf(k, sizeof k, "gen.rb%d.conv_%d.bias", i, conv_idx); const float* cb = need(k);
             Op cv = conv_op(ab, cw, cb, B, r, f, 1, epi);
-            out_dense(cv.conv, y, r, f);
-            if (epi == EPI_RES) aux_dense(cv.conv, res, res_r, f, res_shift);
+            set_out_dense(cv.conv, y, r, f);
+            if (epi == EPI_RES) set_aux_dense(cv.conv, res, res_r, f, res_shift);
             h->ops.push_back(cv);
             return MSR_OK;
         };
@@ -713,6 +718,16 @@ int plan_pix2pix(msr_handle* h) {
     return MSR_OK;
 }
 
+int ensure_conv_partial(msr_handle* h, size_t floats) {
+    if (floats <= h->conv_partial_floats) return MSR_OK;
+    if (h->conv_partial) HIPCHK(h, hipFree(h->conv_partial));
+    h->conv_partial = nullptr;
+    HIPCHK(h, hipMalloc(&h->conv_partial, floats * sizeof(float)));
+    h->total_bytes += (floats - h->conv_partial_floats) * sizeof(float);
+    h->conv_partial_floats = floats;
+    return MSR_OK;
+}
+
 int ensure_plan(msr_handle* h) {
     if (h->planned) return MSR_OK;
     for (auto& s : h->specs)
@@ -723,7 +738,13 @@ int ensure_plan(msr_handle* h) {
     int rc = h->variant == MSR_PIX2PIX ? plan_pix2pix(h) : plan_spade(h);
     if (rc) return rc;
     h->fwd_flops = 0;
-    for (auto& op : h->ops) h->fwd_flops += op.flops;
+    size_t need = 0;
+    for (auto& op : h->ops) {
+        h->fwd_flops += op.flops;
+        if (op.type == OP_CONV && op.conv.ksplit > 1)
+            need = std::max(need, (size_t)op.conv.ksplit * op.conv.B * op.conv.Hout * op.conv.Wout * op.conv.N);
+    }
+    { int rc2 = ensure_conv_partial(h, need); if (rc2) return rc2; }
     HIPCHK(h, hipDeviceSynchronize());
     h->planned = true;
     return MSR_OK;
@@ -761,7 +782,13 @@ int msr_forward(msr_handle* h, const float* in_dev, const float* eps_dev, float*
         hipError_t e = hipSuccess;
         int fam = 0;
         switch (op.type) {
-            case OP_CONV: fam = FAM_CONV; e = launch_conv_igemm(op.conv, op.epi, op.tile, s); break;
+            case OP_CONV: {
+                fam = FAM_CONV;
+                ConvParams cp = op.conv;
+                cp.partial = h->conv_partial;
+                e = launch_conv_igemm(cp, op.epi, op.tile, s);
+                break;
+            }
             case OP_SMALLCIN: {
                 fam = FAM_SMALLCIN;
                 SmallCinParams p = op.sc;
@@ -818,6 +845,38 @@ int msr_forward_flops(const msr_handle* hc, double* flops) {
     int rc = ensure_plan(h);
     if (rc) return rc;
     *flops = h->fwd_flops;
+    return MSR_OK;
+}
+
+int msr_op_conv3x3(msr_handle* h, const float* in_dev, const float* wt_dev, const float* bias_dev, float* out_dev,
+                   int32_t B, int32_t rout, int32_t Cin, int32_t N, int32_t stride, int32_t epilogue,
+                   const float* aux_dev, int32_t aux_shift, const float* mean_dev, const float* std_dev,
+                   int32_t out_padded, int32_t tile, void* stream) {
+    if (!h) return MSR_ERR_INVALID;
+    if (!in_dev || !wt_dev || !bias_dev || !out_dev || B < 1 || rout < 1 || (stride != 1 && stride != 2))
+        return fail(h, MSR_ERR_INVALID, "msr_op_conv3x3: bad argument");
+    if (epilogue < EPI_BIAS || epilogue > EPI_SPADE || (epilogue != EPI_BIAS && !aux_dev) ||
+        (epilogue == EPI_SPADE && (!mean_dev || !std_dev)))
+        return fail(h, MSR_ERR_INVALID, "msr_op_conv3x3: epilogue %d needs aux / mean / std", epilogue);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    Padded in; in.base = const_cast<float*>(in_dev); in.r = rout * stride; in.C = Cin;
+    Op op = conv_op(in, wt_dev, bias_dev, B, rout, N, stride, epilogue);
+    const int Cout = epilogue == EPI_SPADE ? N / 2 : N;
+    if (out_padded) { Padded o; o.base = out_dev; o.r = rout; o.C = Cout; set_out_padded(op.conv, o); }
+    else set_out_dense(op.conv, out_dev, rout, Cout);
+    if (epilogue != EPI_BIAS) set_aux_dense(op.conv, aux_dev, rout >> aux_shift, Cout, aux_shift);
+    op.conv.mean = mean_dev; op.conv.stdv = std_dev;
+    if (tile >= 0) {
+        op.tile = tile & 0xFF;
+        op.conv.ksplit = (tile >> 8) > 0 ? (tile >> 8) : 1;    // explicit tile: explicit split (default none)
+    }
+    if (op.conv.ksplit > 1) {
+        int rc = ensure_conv_partial(h, (size_t)op.conv.ksplit * B * rout * rout * N);
+        if (rc) return rc;
+        op.conv.partial = h->conv_partial;
+    }
+    hipError_t e = launch_conv_igemm(op.conv, epilogue, op.tile, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(h, MSR_ERR_INVALID, "conv launch rejected (shape not tileable?): %s", hipGetErrorString(e));
     return MSR_OK;
 }
 

@@ -21,8 +21,8 @@ namespace msr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-static constexpr int BKC = 32;  // channels per K-step
-static constexpr int BKP = 36;  // LDS row pitch in floats (32 + 4 pad)
+// K-step = BKC channels of one tap; LDS rows are BKC + 4 floats.  Both pitches (36 and 20 floats) put the 16
+// lanes of a ds_read_b128 group on 16 distinct 16-byte slots, i.e. the fragment reads are conflict-free.
 
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     // Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous range of logical tiles so
@@ -35,17 +35,20 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 struct TileGeom {
     int th_l, tw_l, tb;            // log2 tile height/width, samples per tile
     int tiles_x, tiles_y, tiles_b, tiles_n;
+    int tiles_mn;                  // tiles_x * tiles_y * tiles_b * tiles_n (the grid is ksplit times that)
 };
 
-template <int WM, int WN, int MT, int NT, int EPI>
-__global__ void __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <int WM, int WN, int MT, int NT, int BKC, int EPI>
+__global__ void __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2, BKC == 16 ? 3 : 2)))
 conv_igemm_f32(const ConvParams p, const TileGeom g) {
     constexpr int NTHR = WM * WN * 64;
     constexpr int BM = WM * MT * 32;
     constexpr int BN = WN * NT * 32;
-    constexpr int A_ITEMS = BM * 8 / NTHR;
-    constexpr int B_ITEMS = BN * 8 / NTHR;
-    static_assert(BM * 8 % NTHR == 0 && BN * 8 % NTHR == 0, "staging split");
+    constexpr int BKP = BKC + 4;
+    constexpr int SEGS = BKC / 4;            // 16-byte segments per staged row
+    constexpr int A_ITEMS = BM * SEGS / NTHR;
+    constexpr int B_ITEMS = BN * SEGS / NTHR;
+    static_assert(BM * SEGS % NTHR == 0 && BN * SEGS % NTHR == 0, "staging split");
     static_assert(EPI != EPI_SPADE || NT % 2 == 0, "SPADE epilogue pairs gamma/beta sub-tiles");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -58,7 +61,9 @@ conv_igemm_f32(const ConvParams p, const TileGeom g) {
     const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5, l31 = lane & 31;
 
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bid_all = xcd_remap(blockIdx.x, gridDim.x);
+    const int ks = bid_all / g.tiles_mn;          // split-K range index (0 when ksplit == 1)
+    const int bid = bid_all - ks * g.tiles_mn;
     const int tn = bid % g.tiles_n;
     int tmi = bid / g.tiles_n;
     const int tx0 = (tmi % g.tiles_x) << g.tw_l;
@@ -74,7 +79,7 @@ conv_igemm_f32(const ConvParams p, const TileGeom g) {
 #pragma unroll
     for (int q = 0; q < A_ITEMS; ++q) {
         const int idx = tid + q * NTHR;
-        const int row = idx >> 3, seg = idx & 7;
+        const int row = idx / SEGS, seg = idx % SEGS;
         const int tx = row & twm, ty = (row >> g.tw_l) & thm, tbi = row >> (g.tw_l + g.th_l);
         int b = b0 + tbi;
         b = b < p.B ? b : p.B - 1;   // rows past the batch read valid memory and are dropped in the epilogue
@@ -86,7 +91,7 @@ conv_igemm_f32(const ConvParams p, const TileGeom g) {
 #pragma unroll
     for (int q = 0; q < B_ITEMS; ++q) {
         const int idx = tid + q * NTHR;
-        const int row = idx >> 3, seg = idx & 7;
+        const int row = idx / SEGS, seg = idx % SEGS;
         b_goff[q] = (n0 + row) * p.Cin + seg * 4;
         b_loff[q] = row * BKP + seg * 4;
     }
@@ -111,40 +116,73 @@ conv_igemm_f32(const ConvParams p, const TileGeom g) {
     const int steps = taps * chunks;
     const size_t w_tap_stride = (size_t)p.N * p.Cin;
 
-    // K-step iterator: channel chunk outer, tap inner (kh, kw), kept as running scalars (no divisions).
-    int it_kh = 0, it_kw = 0;
-    const float* a_src = p.in;               // + kh*in_py + kw*Cin + cc*BKC
-    const float* b_src = p.wt;               // + tap*N*Cin + cc*BKC
+    // K-step iterator, kept as running scalars (no divisions in the loop).  With split-K this workgroup owns steps
+    // [t_begin, t_end).  Order: BKC = 32 -> channel chunk outer, tap inner; BKC = 16 -> tap outer, chunk inner, so
+    // that consecutive steps read the two 64-byte halves of the same 128-byte lines.
+    const int t_begin = (int)((long)ks * steps / p.ksplit), t_end = (int)((long)(ks + 1) * steps / p.ksplit);
+    int it_kh, it_kw, it_cc;
+    const float* a_src;
+    const float* b_src;
+    if constexpr (BKC == 32) {
+        const int cc0 = t_begin / taps, tap0 = t_begin - cc0 * taps;
+        it_cc = cc0; it_kh = tap0 / p.KW; it_kw = tap0 - it_kh * p.KW;
+        a_src = p.in + (it_kh * p.in_py + it_kw * p.Cin + cc0 * BKC);
+        b_src = p.wt + ((size_t)tap0 * w_tap_stride + cc0 * BKC);
+    } else {
+        const int tap0 = t_begin / chunks, cc0 = t_begin - tap0 * chunks;
+        it_cc = cc0; it_kh = tap0 / p.KW; it_kw = tap0 - it_kh * p.KW;
+        a_src = p.in + (it_kh * p.in_py + it_kw * p.Cin + cc0 * BKC);
+        b_src = p.wt + ((size_t)tap0 * w_tap_stride + cc0 * BKC);
+    }
 
-    // Staging registers.  Everything below is written so that ra/rb stay in VGPRs: fixed trip counts,
-    // compile-time indices, and no conditional around the load/write pair (the last K-step is peeled).
     // Named scalars, not arrays: hipcc leaves a float4 array that crosses a sched_barrier in scratch memory.
-    static_assert(A_ITEMS == 4 && B_ITEMS == 4, "staging is written for 4 + 4 16-byte items per thread");
+    static_assert((A_ITEMS == 4 || A_ITEMS == 2) && A_ITEMS == B_ITEMS, "staging is written for 2+2 or 4+4 items");
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
 #define MSR_ISSUE_LOADS()                                                                        \
     {                                                                                            \
         ra0 = *reinterpret_cast<const float4*>(a_src + a_goff[0]);                               \
         ra1 = *reinterpret_cast<const float4*>(a_src + a_goff[1]);                               \
-        ra2 = *reinterpret_cast<const float4*>(a_src + a_goff[2]);                               \
-        ra3 = *reinterpret_cast<const float4*>(a_src + a_goff[3]);                               \
+        if constexpr (A_ITEMS == 4) {                                                            \
+            ra2 = *reinterpret_cast<const float4*>(a_src + a_goff[2]);                           \
+            ra3 = *reinterpret_cast<const float4*>(a_src + a_goff[3]);                           \
+        }                                                                                        \
         rb0 = *reinterpret_cast<const float4*>(b_src + b_goff[0]);                               \
         rb1 = *reinterpret_cast<const float4*>(b_src + b_goff[1]);                               \
-        rb2 = *reinterpret_cast<const float4*>(b_src + b_goff[2]);                               \
-        rb3 = *reinterpret_cast<const float4*>(b_src + b_goff[3]);                               \
+        if constexpr (B_ITEMS == 4) {                                                            \
+            rb2 = *reinterpret_cast<const float4*>(b_src + b_goff[2]);                           \
+            rb3 = *reinterpret_cast<const float4*>(b_src + b_goff[3]);                           \
+        }                                                                                        \
     }
 #define MSR_ADVANCE()                                                                            \
     {                                                                                            \
-        ++it_kw;                                                                                 \
-        a_src += p.Cin;                                                                          \
-        b_src += w_tap_stride;                                                                   \
-        if (it_kw == p.KW) {                                                                     \
-            it_kw = 0;                                                                           \
-            ++it_kh;                                                                             \
-            a_src += p.in_py - p.KW * p.Cin;                                                     \
-            if (it_kh == p.KH) {                                                                 \
-                it_kh = 0;                                                                       \
-                a_src += BKC - p.KH * p.in_py;                                                   \
-                b_src += BKC - (size_t)taps * w_tap_stride;                                      \
+        if constexpr (BKC == 32) {                                                               \
+            ++it_kw;                                                                             \
+            a_src += p.Cin;                                                                      \
+            b_src += w_tap_stride;                                                               \
+            if (it_kw == p.KW) {                                                                 \
+                it_kw = 0;                                                                       \
+                ++it_kh;                                                                         \
+                a_src += p.in_py - p.KW * p.Cin;                                                 \
+                if (it_kh == p.KH) {                                                             \
+                    it_kh = 0;                                                                   \
+                    a_src += BKC - p.KH * p.in_py;                                               \
+                    b_src += BKC - (size_t)taps * w_tap_stride;                                  \
+                }                                                                                \
+            }                                                                                    \
+        } else {                                                                                 \
+            ++it_cc;                                                                             \
+            a_src += BKC;                                                                        \
+            b_src += BKC;                                                                        \
+            if (it_cc == chunks) {                                                               \
+                it_cc = 0;                                                                       \
+                ++it_kw;                                                                         \
+                a_src += p.Cin - chunks * BKC;                                                   \
+                b_src += w_tap_stride - chunks * BKC;                                            \
+                if (it_kw == p.KW) {                                                             \
+                    it_kw = 0;                                                                   \
+                    ++it_kh;                                                                     \
+                    a_src += p.in_py - p.KW * p.Cin;                                             \
+                }                                                                                \
             }                                                                                    \
         }                                                                                        \
     }
@@ -154,12 +192,16 @@ conv_igemm_f32(const ConvParams p, const TileGeom g) {
         float* b_ = Bs + (buf) * BN * BKP;                                                       \
         *reinterpret_cast<float4*>(a_ + a_loff[0]) = ra0;                                        \
         *reinterpret_cast<float4*>(a_ + a_loff[1]) = ra1;                                        \
-        *reinterpret_cast<float4*>(a_ + a_loff[2]) = ra2;                                        \
-        *reinterpret_cast<float4*>(a_ + a_loff[3]) = ra3;                                        \
+        if constexpr (A_ITEMS == 4) {                                                            \
+            *reinterpret_cast<float4*>(a_ + a_loff[2]) = ra2;                                    \
+            *reinterpret_cast<float4*>(a_ + a_loff[3]) = ra3;                                    \
+        }                                                                                        \
         *reinterpret_cast<float4*>(b_ + b_loff[0]) = rb0;                                        \
         *reinterpret_cast<float4*>(b_ + b_loff[1]) = rb1;                                        \
-        *reinterpret_cast<float4*>(b_ + b_loff[2]) = rb2;                                        \
-        *reinterpret_cast<float4*>(b_ + b_loff[3]) = rb3;                                        \
+        if constexpr (B_ITEMS == 4) {                                                            \
+            *reinterpret_cast<float4*>(b_ + b_loff[2]) = rb2;                                    \
+            *reinterpret_cast<float4*>(b_ + b_loff[3]) = rb3;                                    \
+        }                                                                                        \
     }
 #define MSR_COMPUTE(buf)                                                                         \
     {                                                                                            \
@@ -187,7 +229,7 @@ conv_igemm_f32(const ConvParams p, const TileGeom g) {
     MSR_WRITE_LDS(0);
     __syncthreads();
     int cur = 0;
-    for (int t = 0; t < steps - 1; ++t) {
+    for (int t = t_begin; t < t_end - 1; ++t) {
         MSR_ADVANCE();
         MSR_ISSUE_LOADS();       // global loads of step t+1 fly while the MFMAs of step t run
         __builtin_amdgcn_sched_barrier(0);   // keep hipcc from sinking the loads below the MFMAs
@@ -206,6 +248,23 @@ conv_igemm_f32(const ConvParams p, const TileGeom g) {
     // ---- epilogue -----------------------------------------------------------------------------------
     // C/D map of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
     // Per-column constants (bias, SPADE mean / std) are loaded once, before the row loops.
+    if constexpr (EPI == EPI_PARTIAL) {
+        float* pbase = p.partial + (size_t)ks * ((size_t)p.B * p.Hout * p.Wout * p.N);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int tx = row & twm, ty = (row >> g.tw_l) & thm, tbi = row >> (g.tw_l + g.th_l);
+                const int bb = b0 + tbi;
+                if (tbi >= g.tb || bb >= p.B) continue;
+                float* orow = pbase + (((size_t)bb * p.Hout + ty0 + ty) * p.Wout + tx0 + tx) * p.N;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) orow[n0 + (wn * NT + n) * 32 + l31] = acc[m][n][r];
+            }
+        }
+        return;
+    }
     constexpr int NCH = EPI == EPI_SPADE ? NT / 2 : NT;
     float cb0[NCH], cb1[NCH], cmean[NCH], cstd[NCH];
     int ccol[NCH];
@@ -263,29 +322,91 @@ conv_igemm_f32(const ConvParams p, const TileGeom g) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-template <int WM, int WN, int MT, int NT>
+// splitk_epilogue: sums the ksplit partial accumulators in a fixed order (deterministic) and applies the same
+// epilogue the fused kernel would have applied.  One thread per (pixel, 4 channels).
+// ------------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ void __launch_bounds__(256) splitk_epilogue_kernel(const ConvParams p) {
+    const int Cout = EPI == EPI_SPADE ? p.N / 2 : p.N;
+    const int quads = Cout / 4;
+    const long M = (long)p.B * p.Hout * p.Wout;
+    const long total = M * quads;
+    const size_t pstride = (size_t)M * p.N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int q = (int)(i % quads);
+        const long pix = i / quads;
+        const int x = (int)(pix % p.Wout);
+        const int y = (int)((pix / p.Wout) % p.Hout);
+        const int b = (int)(pix / ((long)p.Wout * p.Hout));
+        const int c = q * 4;
+        const int col = EPI == EPI_SPADE ? (c / 32) * 64 + (c % 32) : c;
+        const float* pp = p.partial + (size_t)pix * p.N + col;
+        float4 a = *reinterpret_cast<const float4*>(pp);
+        float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (EPI == EPI_SPADE) bsum = *reinterpret_cast<const float4*>(pp + 32);
+        for (int k = 1; k < p.ksplit; ++k) {
+            const float4 t = *reinterpret_cast<const float4*>(pp + k * pstride);
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+            if constexpr (EPI == EPI_SPADE) {
+                const float4 u = *reinterpret_cast<const float4*>(pp + k * pstride + 32);
+                bsum.x += u.x; bsum.y += u.y; bsum.z += u.z; bsum.w += u.w;
+            }
+        }
+        const float4 b0v = *reinterpret_cast<const float4*>(p.bias + col);
+        float4 v = make_float4(a.x + b0v.x, a.y + b0v.y, a.z + b0v.z, a.w + b0v.w);
+        if constexpr (EPI == EPI_RES || EPI == EPI_SPADE) {
+            const float4 xv = *reinterpret_cast<const float4*>(p.aux + (size_t)b * p.aux_pb +
+                                                               (size_t)(y >> p.aux_shift) * p.aux_py +
+                                                               (size_t)(x >> p.aux_shift) * p.aux_px + c);
+            if constexpr (EPI == EPI_RES) {
+                v.x += xv.x; v.y += xv.y; v.z += xv.z; v.w += xv.w;
+            } else {
+                const float4 b1v = *reinterpret_cast<const float4*>(p.bias + col + 32);
+                const float4 mu = *reinterpret_cast<const float4*>(p.mean + c);
+                const float4 sd = *reinterpret_cast<const float4*>(p.stdv + c);
+                v.x = v.x * ((xv.x - mu.x) / sd.x) + (bsum.x + b1v.x);
+                v.y = v.y * ((xv.y - mu.y) / sd.y) + (bsum.y + b1v.y);
+                v.z = v.z * ((xv.z - mu.z) / sd.z) + (bsum.z + b1v.z);
+                v.w = v.w * ((xv.w - mu.w) / sd.w) + (bsum.w + b1v.w);
+                v.x = v.x >= 0.f ? v.x : v.x * p.slope; v.y = v.y >= 0.f ? v.y : v.y * p.slope;
+                v.z = v.z >= 0.f ? v.z : v.z * p.slope; v.w = v.w >= 0.f ? v.w : v.w * p.slope;
+            }
+        }
+        float* o = p.out + (size_t)p.out_off + (size_t)b * p.out_pb + (size_t)y * p.out_py + (size_t)x * p.out_px + c;
+        *reinterpret_cast<float4*>(o) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+template <int WM, int WN, int MT, int NT, int BKC>
 struct TileCfg {
     static constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NTHR = WM * WN * 64;
-    static constexpr size_t LDS = (size_t)(2 * BM + 2 * BN) * BKP * sizeof(float);
+    static constexpr size_t LDS = (size_t)(2 * BM + 2 * BN) * (BKC + 4) * sizeof(float);
 };
-using CfgBig = TileCfg<2, 2, 2, 2>;     // 128 x 128, 4 waves, 72 KiB LDS -> 2 workgroups per CU
-using CfgSmall = TileCfg<2, 1, 1, 2>;   //  64 x  64, 2 waves, 36 KiB LDS -> 4 workgroups per CU
+// TILE_128x128   : 4 waves, K-step 32, 72 KiB LDS -> 2 workgroups (2 waves / SIMD) per CU
+// TILE_64x64     : 2 waves, K-step 32, 36 KiB LDS -> 4 workgroups per CU (low-resolution layers, with split-K)
+// TILE_128x128_K16: 4 waves, K-step 16, 40 KiB LDS -> 3 workgroups (3 waves / SIMD) per CU
 
-template <int WM, int WN, int MT, int NT, int EPI>
+template <int WM, int WN, int MT, int NT, int BKC, int EPI>
 static hipError_t set_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<WM, WN, MT, NT, EPI>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)TileCfg<WM, WN, MT, NT>::LDS);
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<WM, WN, MT, NT, BKC, EPI>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)TileCfg<WM, WN, MT, NT, BKC>::LDS);
+}
+
+template <int WM, int WN, int MT, int NT, int BKC>
+static hipError_t set_attr_all() {
+    hipError_t e;
+    if ((e = set_attr<WM, WN, MT, NT, BKC, EPI_BIAS>()) != hipSuccess) return e;
+    if ((e = set_attr<WM, WN, MT, NT, BKC, EPI_RES>()) != hipSuccess) return e;
+    if ((e = set_attr<WM, WN, MT, NT, BKC, EPI_SPADE>()) != hipSuccess) return e;
+    return set_attr<WM, WN, MT, NT, BKC, EPI_PARTIAL>();
 }
 
 hipError_t conv_igemm_init() {
     hipError_t e;
-    if ((e = set_attr<2, 2, 2, 2, EPI_BIAS>()) != hipSuccess) return e;
-    if ((e = set_attr<2, 2, 2, 2, EPI_RES>()) != hipSuccess) return e;
-    if ((e = set_attr<2, 2, 2, 2, EPI_SPADE>()) != hipSuccess) return e;
-    if ((e = set_attr<2, 1, 1, 2, EPI_BIAS>()) != hipSuccess) return e;
-    if ((e = set_attr<2, 1, 1, 2, EPI_RES>()) != hipSuccess) return e;
-    if ((e = set_attr<2, 1, 1, 2, EPI_SPADE>()) != hipSuccess) return e;
-    return hipSuccess;
+    if ((e = set_attr_all<2, 2, 2, 2, 32>()) != hipSuccess) return e;
+    if ((e = set_attr_all<2, 1, 1, 2, 32>()) != hipSuccess) return e;
+    return set_attr_all<2, 2, 2, 2, 16>();
 }
 
 static int ilog2_floor(int v) {
@@ -294,7 +415,7 @@ static int ilog2_floor(int v) {
     return l;
 }
 
-static bool make_geom(const ConvParams& p, int BM, int BN, TileGeom& g) {
+static bool make_geom(const ConvParams& p, int BM, int BN, int BKC, TileGeom& g) {
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
     if (!pow2(p.Hout) || !pow2(p.Wout)) return false;
     if (p.N % BN || p.Cin % BKC) return false;
@@ -310,30 +431,57 @@ static bool make_geom(const ConvParams& p, int BM, int BN, TileGeom& g) {
     g.tiles_y = p.Hout / th;
     g.tiles_b = (p.B + tb - 1) / tb;
     g.tiles_n = p.N / BN;
+    g.tiles_mn = g.tiles_x * g.tiles_y * g.tiles_b * g.tiles_n;
     return true;
 }
 
-int conv_pick_tile(int M, int N) {
+int conv_pick_tile(int M, int N, int epilogue) {
     // The big tile needs >= ~2 waves of workgroups per CU to hide its barrier; otherwise take the small one.
+    // Measured on MI355X (tests/gpu_conv_bench.py): the 16-channel K-step (3 workgroups per CU) is ~8 % faster
+    // than the 32-channel one for the SPADE epilogue (its long epilogue is covered by a third resident
+    // workgroup) and ~3 % slower for plain long-K convs.
     const long big_blocks = (long)((M + 127) / 128) * (N / 128);
-    return (N % 128 == 0 && big_blocks >= 512) ? TILE_128x128 : TILE_64x64;
+    if (N % 128 == 0 && big_blocks >= 512) return epilogue == EPI_SPADE ? TILE_128x128_K16 : TILE_128x128;
+    return TILE_64x64;
 }
 
-template <int WM, int WN, int MT, int NT>
+int conv_pick_ksplit(int M, int N, int ksteps, int tile) {
+    // Low-resolution layers (M = B*r*r of a few hundred pixels) do not produce enough tiles to fill 256 CUs:
+    // cut K so that about 1024 small (512 big) workgroups exist.  Every range keeps >= 4 K-steps.
+    const int bm = tile == TILE_64x64 ? 64 : 128;
+    const long blocks = (long)((M + bm - 1) / bm) * (N / bm);
+    const long want = tile == TILE_64x64 ? 1024 : 512;
+    int ks = 1;
+    while (blocks * ks < want && ks < 16 && ksteps / (ks * 2) >= 4) ks *= 2;
+    return ks;
+}
+
+template <int WM, int WN, int MT, int NT, int BKC>
 static hipError_t launch_cfg(const ConvParams& p, int epi, hipStream_t s) {
-    using C = TileCfg<WM, WN, MT, NT>;
+    using C = TileCfg<WM, WN, MT, NT, BKC>;
     TileGeom g;
-    if (!make_geom(p, C::BM, C::BN, g)) return hipErrorInvalidValue;
-    const int grid = g.tiles_x * g.tiles_y * g.tiles_b * g.tiles_n;
+    if (!make_geom(p, C::BM, C::BN, BKC, g)) return hipErrorInvalidValue;
+    if (p.ksplit > 1) {
+        if (!p.partial || epi == EPI_PARTIAL) return hipErrorInvalidValue;
+        conv_igemm_f32<WM, WN, MT, NT, BKC, EPI_PARTIAL><<<g.tiles_mn * p.ksplit, C::NTHR, C::LDS, s>>>(p, g);
+        const int Cout = epi == EPI_SPADE ? p.N / 2 : p.N;
+        long eb = ((long)p.B * p.Hout * p.Wout * (Cout / 4) + 255) / 256;
+        if (eb > 4096) eb = 4096;
+        if (epi == EPI_BIAS) splitk_epilogue_kernel<EPI_BIAS><<<(int)eb, 256, 0, s>>>(p);
+        else if (epi == EPI_RES) splitk_epilogue_kernel<EPI_RES><<<(int)eb, 256, 0, s>>>(p);
+        else splitk_epilogue_kernel<EPI_SPADE><<<(int)eb, 256, 0, s>>>(p);
+        return hipGetLastError();
+    }
+    const int grid = g.tiles_mn;
     switch (epi) {
         case EPI_BIAS:
-            conv_igemm_f32<WM, WN, MT, NT, EPI_BIAS><<<grid, C::NTHR, C::LDS, s>>>(p, g);
+            conv_igemm_f32<WM, WN, MT, NT, BKC, EPI_BIAS><<<grid, C::NTHR, C::LDS, s>>>(p, g);
             break;
         case EPI_RES:
-            conv_igemm_f32<WM, WN, MT, NT, EPI_RES><<<grid, C::NTHR, C::LDS, s>>>(p, g);
+            conv_igemm_f32<WM, WN, MT, NT, BKC, EPI_RES><<<grid, C::NTHR, C::LDS, s>>>(p, g);
             break;
         case EPI_SPADE:
-            conv_igemm_f32<WM, WN, MT, NT, EPI_SPADE><<<grid, C::NTHR, C::LDS, s>>>(p, g);
+            conv_igemm_f32<WM, WN, MT, NT, BKC, EPI_SPADE><<<grid, C::NTHR, C::LDS, s>>>(p, g);
             break;
         default:
             return hipErrorInvalidValue;
@@ -342,8 +490,9 @@ static hipError_t launch_cfg(const ConvParams& p, int epi, hipStream_t s) {
 }
 
 hipError_t launch_conv_igemm(const ConvParams& p, int epilogue, int tile, hipStream_t s) {
-    if (tile == TILE_128x128) return launch_cfg<2, 2, 2, 2>(p, epilogue, s);
-    return launch_cfg<2, 1, 1, 2>(p, epilogue, s);
+    if (tile == TILE_128x128) return launch_cfg<2, 2, 2, 2, 32>(p, epilogue, s);
+    if (tile == TILE_128x128_K16) return launch_cfg<2, 2, 2, 2, 16>(p, epilogue, s);
+    return launch_cfg<2, 1, 1, 2, 32>(p, epilogue, s);
 }
 
 }  // namespace msr

@@ -19,6 +19,7 @@ enum ConvEpilogue : int {
                     //                                          with UpSampling2D folded into the index)
     EPI_SPADE = 2,  // N = 2C, columns interleaved (gamma block of 32 | beta block of 32):
                     // out = leaky_relu((g+bg) * ((x-mean)/std) + (b+bb))   spade.py:21-24 + blocks.py:30-34
+    EPI_PARTIAL = 3,  // split-K: raw accumulators to partial[ks][B,Hout,Wout,N]; splitk_epilogue finishes
 };
 
 struct ConvParams {
@@ -37,14 +38,17 @@ struct ConvParams {
     int aux_px, aux_py, aux_pb;   // aux pitches
     int aux_shift;                // 1 = aux is at half resolution (nearest 2x up-sample folded in)
     float slope;                  // leaky-relu slope of EPI_SPADE
+    int ksplit;                   // > 1: the K loop is cut into ksplit ranges, one workgroup each (low-res layers)
+    float* partial;               // [ksplit][B*Hout*Wout][N] workspace for split-K
 };
 
-enum ConvTile : int { TILE_128x128 = 0, TILE_64x64 = 1 };
+enum ConvTile : int { TILE_128x128 = 0, TILE_64x64 = 1, TILE_128x128_K16 = 2 };
 
 hipError_t conv_igemm_init();   // sets dynamic-LDS attributes once
 hipError_t launch_conv_igemm(const ConvParams& p, int epilogue, int tile, hipStream_t s);
-// picks the tile for a problem size (fills the chip for the low-resolution layers)
-int conv_pick_tile(int M, int N);
+// picks the tile and the K split for a problem size (fills the chip for the low-resolution layers)
+int conv_pick_tile(int M, int N, int epilogue);
+int conv_pick_ksplit(int M, int N, int ksteps, int tile);
 
 // ---------------------------------------------------------------------------------------------
 // Small kernels (memory-bound or tiny)
@@ -87,7 +91,7 @@ struct NormActParams {
 hipError_t launch_norm_act(const NormActParams& p, hipStream_t s);
 
 // y[b, n] = sum_k x[b, k] * W[k, n] (+ bias) for tiny M = B <= 16: split-K weight streaming.
-int dense_splits(int K);
+size_t dense_partial_floats(int B, int K, int N);
 hipError_t launch_dense(const float* x, const float* W, const float* bias, float* partial, float* y, int B, int K,
                         int N, hipStream_t s);
 

@@ -19,10 +19,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 //                          networks.py:16-18): t = 2y + kh valid in [0,S), source row = t.
 // One thread owns 4 output channels (weights for its 18 taps live in registers) and walks pixels.
 // ------------------------------------------------------------------------------------------------
-template <int COUT>
+template <int COUT, int PX>   // PX adjacent output pixels per thread share their 3 x (PX+2) source window
 __global__ void __launch_bounds__(256) conv_smallcin_kernel(const SmallCinParams p) {
-    constexpr int QUADS = COUT / 4;          // threads per pixel
-    constexpr int PIX = 256 / QUADS;         // pixels per block pass
+    constexpr int QUADS = COUT / 4;          // threads per pixel group
+    constexpr int GRP = 256 / QUADS;         // pixel groups per block pass
     const int q = threadIdx.x % QUADS;
     const int pl = threadIdx.x / QUADS;
     float4 w[18];
@@ -30,54 +30,74 @@ __global__ void __launch_bounds__(256) conv_smallcin_kernel(const SmallCinParams
     for (int t = 0; t < 18; ++t) w[t] = *reinterpret_cast<const float4*>(p.w + t * COUT + q * 4);
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) bias = *reinterpret_cast<const float4*>(p.bias + q * 4);
-    const long total = (long)p.B * p.Hout * p.Hout;
-    for (long pix = (long)blockIdx.x * PIX + pl; pix < total; pix += (long)gridDim.x * PIX) {
-        const int x = (int)(pix % p.Hout);
-        const int y = (int)((pix / p.Hout) % p.Hout);
-        const int b = (int)(pix / ((long)p.Hout * p.Hout));
+    const int gpr = p.Hout / PX;             // groups per output row
+    const long total = (long)p.B * p.Hout * gpr;
+    for (long grp = (long)blockIdx.x * GRP + pl; grp < total; grp += (long)gridDim.x * GRP) {
+        const int x0 = (int)(grp % gpr) * PX;
+        const int y = (int)((grp / gpr) % p.Hout);
+        const int b = (int)(grp / ((long)gpr * p.Hout));
         const float* sb = p.src + (size_t)b * p.S * p.S * 2;
-        float4 acc = bias;
+        // source window: rows kh = 0..2, columns j = 0..(PX-1)*ay+2  (ay = 1: PX+2 columns; ay = 2: 2*PX+1)
+        constexpr int WMAX = 2 * PX + 1;
+        float2 win[3][WMAX];
+        const int ncol = (PX - 1) * p.ay + 3;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int ty = y * p.ay + kh + p.cy;
             const bool oky = ty >= 0 && ty < p.lim;
-            const int sy = ty * p.f + p.o;
+            const size_t rowoff = (size_t)(ty * p.f + p.o) * p.S;
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int tx = x * p.ay + kw + p.cy;
-                const bool ok = oky && tx >= 0 && tx < p.lim;
-                float2 v = make_float2(0.f, 0.f);
-                if (ok) v = *reinterpret_cast<const float2*>(sb + ((size_t)sy * p.S + (tx * p.f + p.o)) * 2);
-                const float4 w0 = w[(kh * 3 + kw) * 2], w1 = w[(kh * 3 + kw) * 2 + 1];
-                acc.x += v.x * w0.x; acc.y += v.x * w0.y; acc.z += v.x * w0.z; acc.w += v.x * w0.w;
-                acc.x += v.y * w1.x; acc.y += v.y * w1.y; acc.z += v.y * w1.z; acc.w += v.y * w1.w;
+            for (int j = 0; j < WMAX; ++j) {
+                const int tx = x0 * p.ay + j + p.cy;
+                const bool ok = oky && j < ncol && tx >= 0 && tx < p.lim;
+                win[kh][j] = ok ? *reinterpret_cast<const float2*>(sb + (rowoff + (tx * p.f + p.o)) * 2)
+                                : make_float2(0.f, 0.f);
             }
         }
-        if (p.act == 1) {
-            acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
-        } else if (p.act == 2) {
-            acc.x = acc.x >= 0.f ? acc.x : acc.x * p.slope; acc.y = acc.y >= 0.f ? acc.y : acc.y * p.slope;
-            acc.z = acc.z >= 0.f ? acc.z : acc.z * p.slope; acc.w = acc.w >= 0.f ? acc.w : acc.w * p.slope;
+        float* o = p.out + (size_t)p.out_off + (size_t)b * p.out_pb + (size_t)y * p.out_py + (size_t)x0 * p.out_px + q * 4;
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+            float4 acc = bias;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    // column of tap kw for pixel i: i*ay + kw (ay is 1 or 2; both instantiated branches are static)
+                    const float2 v = p.ay == 1 ? win[kh][(i + kw) < WMAX ? (i + kw) : 0]
+                                               : win[kh][(2 * i + kw) < WMAX ? (2 * i + kw) : 0];
+                    const float4 w0 = w[(kh * 3 + kw) * 2], w1 = w[(kh * 3 + kw) * 2 + 1];
+                    acc.x += v.x * w0.x; acc.y += v.x * w0.y; acc.z += v.x * w0.z; acc.w += v.x * w0.w;
+                    acc.x += v.y * w1.x; acc.y += v.y * w1.y; acc.z += v.y * w1.z; acc.w += v.y * w1.w;
+                }
+            }
+            if (p.act == 1) {
+                acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+            } else if (p.act == 2) {
+                acc.x = acc.x >= 0.f ? acc.x : acc.x * p.slope; acc.y = acc.y >= 0.f ? acc.y : acc.y * p.slope;
+                acc.z = acc.z >= 0.f ? acc.z : acc.z * p.slope; acc.w = acc.w >= 0.f ? acc.w : acc.w * p.slope;
+            }
+            *reinterpret_cast<float4*>(o + (size_t)i * p.out_px) = acc;
         }
-        float* o = p.out + (size_t)p.out_off + (size_t)b * p.out_pb + (size_t)y * p.out_py + (size_t)x * p.out_px + q * 4;
-        *reinterpret_cast<float4*>(o) = acc;
     }
 }
 
-hipError_t launch_conv_smallcin(const SmallCinParams& p, hipStream_t s) {
-    const long total = (long)p.B * p.Hout * p.Hout;
-    if (p.Cout == 128) {
-        long blocks = (total + 7) / 8;
-        if (blocks > 4096) blocks = 4096;
-        conv_smallcin_kernel<128><<<(int)blocks, 256, 0, s>>>(p);
-    } else if (p.Cout == 64) {
-        long blocks = (total + 15) / 16;
-        if (blocks > 4096) blocks = 4096;
-        conv_smallcin_kernel<64><<<(int)blocks, 256, 0, s>>>(p);
-    } else {
-        return hipErrorInvalidValue;
-    }
+template <int COUT>
+static hipError_t launch_smallcin_t(const SmallCinParams& p, hipStream_t s) {
+    constexpr int GRP = 256 / (COUT / 4);
+    const int px = (p.Hout % 4 == 0) ? 4 : 1;
+    const long total = (long)p.B * p.Hout * (p.Hout / px);
+    long blocks = (total + GRP - 1) / GRP;
+    if (blocks > 8192) blocks = 8192;
+    if (px == 4) conv_smallcin_kernel<COUT, 4><<<(int)blocks, 256, 0, s>>>(p);
+    else conv_smallcin_kernel<COUT, 1><<<(int)blocks, 256, 0, s>>>(p);
     return hipGetLastError();
+}
+
+hipError_t launch_conv_smallcin(const SmallCinParams& p, hipStream_t s) {
+    if (p.ay != 1 && p.ay != 2) return hipErrorInvalidValue;
+    if (p.Cout == 128) return launch_smallcin_t<128>(p, s);
+    if (p.Cout == 64) return launch_smallcin_t<64>(p, s);
+    return hipErrorInvalidValue;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -85,7 +105,7 @@ hipError_t launch_conv_smallcin(const SmallCinParams& p, hipStream_t s) {
 // squares (exact to fp64 rounding, so the one-pass form equals TF's two-pass moments at fp32 precision).
 // Stage 1: grid (chunks, G); thread = (channel quad, pixel slot); Stage 2: one thread per (g, c).
 // ------------------------------------------------------------------------------------------------
-static constexpr int MOM_PIX_PER_CHUNK = 512;
+static constexpr int MOM_PIX_PER_CHUNK = 128;   // small chunks: thousands of workgroups keep enough bytes in flight
 
 int moments_chunks(int P) { return (P + MOM_PIX_PER_CHUNK - 1) / MOM_PIX_PER_CHUNK; }
 
@@ -106,8 +126,23 @@ __global__ void __launch_bounds__(256) moments_partial_kernel(const float* __res
         const int slot = threadIdx.x / tq;
         double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
         if (q < quads) {
-            for (int pix = p0 + slot; pix < p1; pix += slots) {
-                const float4 v = *reinterpret_cast<const float4*>(xg + (size_t)pix * C + q * 4);
+            // 4 independent 16-byte loads in flight per thread; short fp32 runs flushed into fp64 accumulators
+            const float* base = xg + q * 4;
+            int pix = p0 + slot;
+            for (; pix + 3 * slots < p1; pix += 4 * slots) {
+                const float4 v0 = *reinterpret_cast<const float4*>(base + (size_t)pix * C);
+                const float4 v1 = *reinterpret_cast<const float4*>(base + (size_t)(pix + slots) * C);
+                const float4 v2 = *reinterpret_cast<const float4*>(base + (size_t)(pix + 2 * slots) * C);
+                const float4 v3 = *reinterpret_cast<const float4*>(base + (size_t)(pix + 3 * slots) * C);
+                s[0] += (double)((v0.x + v1.x) + (v2.x + v3.x)); s[1] += (double)((v0.y + v1.y) + (v2.y + v3.y));
+                s[2] += (double)((v0.z + v1.z) + (v2.z + v3.z)); s[3] += (double)((v0.w + v1.w) + (v2.w + v3.w));
+                ss[0] += (double)((v0.x * v0.x + v1.x * v1.x) + (v2.x * v2.x + v3.x * v3.x));
+                ss[1] += (double)((v0.y * v0.y + v1.y * v1.y) + (v2.y * v2.y + v3.y * v3.y));
+                ss[2] += (double)((v0.z * v0.z + v1.z * v1.z) + (v2.z * v2.z + v3.z * v3.z));
+                ss[3] += (double)((v0.w * v0.w + v1.w * v1.w) + (v2.w * v2.w + v3.w * v3.w));
+            }
+            for (; pix < p1; pix += slots) {
+                const float4 v = *reinterpret_cast<const float4*>(base + (size_t)pix * C);
                 s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
                 ss[0] += (double)v.x * v.x; ss[1] += (double)v.y * v.y;
                 ss[2] += (double)v.z * v.z; ss[3] += (double)v.w * v.w;
@@ -131,32 +166,39 @@ __global__ void __launch_bounds__(256) moments_partial_kernel(const float* __res
     }
 }
 
-__global__ void __launch_bounds__(256) moments_final_kernel(const double* __restrict__ partial, int G, int chunks,
+// one workgroup per (group, 32 channels): 32 chunk slots x 32 channels, fixed-order tree -> deterministic
+__global__ void __launch_bounds__(1024) moments_final_kernel(const double* __restrict__ partial, int G, int chunks,
                                                             int C, int P, float eps, float* __restrict__ mean,
                                                             float* __restrict__ stdv) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= G * C) return;
-    const int g = i / C, c = i % C;
+    __shared__ double red[32][32][2];
+    const int cblocks = C / 32;
+    const int g = blockIdx.x / cblocks, c = (blockIdx.x % cblocks) * 32 + (threadIdx.x & 31);
+    const int slot = threadIdx.x >> 5;
     double s = 0, ss = 0;
-    for (int k = 0; k < chunks; ++k) {
-        const double* o = partial + (((size_t)g * chunks + k) * C + c) * 2;
-        s += o[0]; ss += o[1];
+    for (int k = slot; k < chunks; k += 32) {
+        const double2 v = *reinterpret_cast<const double2*>(partial + (((size_t)g * chunks + k) * C + c) * 2);
+        s += v.x; ss += v.y;
     }
-    const double m = s / P;
-    double var = ss / P - m * m;
-    if (var < 0) var = 0;
-    const float mf = (float)m;
-    mean[i] = mf;
-    // the reference adds eps in float32 and takes a float32 sqrt (spade.py:22); mirror that rounding
-    stdv[i] = sqrtf((float)var + eps);
+    red[slot][threadIdx.x & 31][0] = s;
+    red[slot][threadIdx.x & 31][1] = ss;
+    __syncthreads();
+    if (slot == 0) {
+        for (int k = 1; k < 32; ++k) { s += red[k][threadIdx.x][0]; ss += red[k][threadIdx.x][1]; }
+        const double m = s / P;
+        double var = ss / P - m * m;
+        if (var < 0) var = 0;
+        mean[(size_t)g * C + c] = (float)m;
+        // the reference adds eps in float32 and takes a float32 sqrt (spade.py:22); mirror that rounding
+        stdv[(size_t)g * C + c] = sqrtf((float)var + eps);
+    }
 }
 
 hipError_t launch_moments(const float* x, int G, int P, int C, float eps, double* partial, float* mean, float* stdv,
                           hipStream_t s) {
-    if (C % 4) return hipErrorInvalidValue;
+    if (C % 32) return hipErrorInvalidValue;
     const int chunks = moments_chunks(P);
     moments_partial_kernel<<<dim3(chunks, G), 256, 0, s>>>(x, P, C, partial);
-    moments_final_kernel<<<(G * C + 255) / 256, 256, 0, s>>>(partial, G, chunks, C, P, eps, mean, stdv);
+    moments_final_kernel<<<G * (C / 32), 1024, 0, s>>>(partial, G, chunks, C, P, eps, mean, stdv);
     return hipGetLastError();
 }
 
@@ -206,19 +248,30 @@ hipError_t launch_norm_act(const NormActParams& p, hipStream_t s) {
 //   encoder heads: Dense(256) x2 on the 131072-wide flatten (networks.py:31-33)  -> K-split
 //   generator:     Dense(16*sw*sw*64) on the latent (networks.py:41)               -> N-parallel
 // ------------------------------------------------------------------------------------------------
-static constexpr int DENSE_KCH = 256;
+static constexpr int DENSE_KCH = 256;   // largest K chunk (LDS staging of x)
 static constexpr int DENSE_MAXB = 16;
 
-int dense_splits(int K) { return (K + DENSE_KCH - 1) / DENSE_KCH; }
+static int dense_kch(int K, int N) {
+    // enough workgroups to pull the weight matrix at HBM rate: >= 512 blocks of 128 threads
+    const int gx = (N / 4 + 127) / 128;
+    int kch = DENSE_KCH;
+    while (kch > 16 && (long)gx * ((K + kch - 1) / kch) < 512) kch >>= 1;
+    return kch;
+}
+size_t dense_partial_floats(int B, int K, int N) {
+    const int kch = dense_kch(K, N);
+    return (size_t)((K + kch - 1) / kch) * B * N;
+}
 
 __global__ void __launch_bounds__(128) dense_partial_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                                            float* __restrict__ partial, int B, int K, int N) {
+                                                            float* __restrict__ partial, int B, int K, int N,
+                                                            int kch) {
     __shared__ float xs[DENSE_MAXB][DENSE_KCH];
     const int col = (blockIdx.x * 128 + threadIdx.x) * 4;
-    const int k0 = blockIdx.y * DENSE_KCH;
-    const int kn = min(DENSE_KCH, K - k0);
-    for (int i = threadIdx.x; i < B * DENSE_KCH; i += 128) {
-        const int b = i / DENSE_KCH, k = i % DENSE_KCH;
+    const int k0 = blockIdx.y * kch;
+    const int kn = min(kch, K - k0);
+    for (int i = threadIdx.x; i < B * kch; i += 128) {
+        const int b = i / kch, k = i % kch;
         xs[b][k] = k < kn ? x[(size_t)b * K + k0 + k] : 0.f;
     }
     __syncthreads();
@@ -243,22 +296,31 @@ __global__ void __launch_bounds__(128) dense_partial_kernel(const float* __restr
         if (b < B) *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.y * B + b) * N + col) = acc[b];
 }
 
+// 16 outputs x 16 split slots per workgroup; fixed-order combine -> deterministic
 __global__ void __launch_bounds__(256) dense_final_kernel(const float* __restrict__ partial,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           int splits, int B, int N) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= B * N) return;
+    __shared__ float red[16][16];
+    const int lane = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + lane;
     float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += partial[(size_t)k * B * N + i];
-    y[i] = s + (bias ? bias[i % N] : 0.f);
+    if (i < B * N)
+        for (int k = slot; k < splits; k += 16) s += partial[(size_t)k * B * N + i];
+    red[slot][lane] = s;
+    __syncthreads();
+    if (slot == 0 && i < B * N) {
+        for (int k = 1; k < 16; ++k) s += red[k][lane];
+        y[i] = s + (bias ? bias[i % N] : 0.f);
+    }
 }
 
 hipError_t launch_dense(const float* x, const float* W, const float* bias, float* partial, float* y, int B, int K,
                         int N, hipStream_t s) {
     if (B > DENSE_MAXB || N % 4) return hipErrorInvalidValue;
-    const int splits = dense_splits(K);
-    dense_partial_kernel<<<dim3((N / 4 + 127) / 128, splits), 128, 0, s>>>(x, W, partial, B, K, N);
-    dense_final_kernel<<<(B * N + 255) / 256, 256, 0, s>>>(partial, bias, y, splits, B, N);
+    const int kch = dense_kch(K, N);
+    const int splits = (K + kch - 1) / kch;
+    dense_partial_kernel<<<dim3((N / 4 + 127) / 128, splits), 128, 0, s>>>(x, W, partial, B, K, N, kch);
+    dense_final_kernel<<<(B * N + 15) / 16, 256, 0, s>>>(partial, bias, y, splits, B, N);
     return hipGetLastError();
 }
 

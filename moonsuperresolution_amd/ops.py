@@ -1,0 +1,84 @@
+"""Kernel-level host wrappers (parity tests and micro-benchmarks of single HIP kernels through the C ABI)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+EPI_BIAS, EPI_RES, EPI_SPADE = 0, 1, 2
+
+
+class OpContext:
+    """A bare library handle (no weights) for launching single kernels on one device."""
+
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("moonsuperresolution_amd needs a HIP device (MI355X / gfx950); there is no CPU fallback")
+        self.device = torch.device("cuda", device)
+        cfg = _lib.MsrConfig(64, 1, 256, _lib.VARIANT_IDS["gaugan_no_kl"], device, 0)
+        self.h = C.c_void_p()
+        _lib.raise_for(self.lib, None, self.lib.msr_create(C.byref(cfg), C.byref(self.h)), "msr_create")
+
+    def close(self):
+        if self.h:
+            self.lib.msr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def pad_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """[B,r,r,C] -> zero-bordered [B,r+2,r+2,C] (the layout every conv_igemm input uses)."""
+    B, r, _, Cc = x.shape
+    p = torch.zeros((B, r + 2, r + 2, Cc), dtype=torch.float32, device=x.device)
+    p[:, 1:-1, 1:-1] = x
+    return p
+
+
+def kernel_layout(w_hwio: torch.Tensor) -> torch.Tensor:
+    """HWIO [3,3,Cin,Cout] -> [9][Cout][Cin]."""
+    kh, kw, ci, co = w_hwio.shape
+    return w_hwio.reshape(kh * kw, ci, co).permute(0, 2, 1).contiguous()
+
+
+def spade_layout(wg: torch.Tensor, wb: torch.Tensor, bg: torch.Tensor, bb: torch.Tensor):
+    """gamma / beta HWIO kernels -> one [9][2C][Cin] tensor with (32 gamma | 32 beta) interleaved rows + its bias."""
+    Cc = wg.shape[3]
+    c = torch.arange(Cc, device=wg.device)
+    rows_g = (c // 32) * 64 + (c % 32)
+    rows_b = rows_g + 32
+    kg, kb = kernel_layout(wg), kernel_layout(wb)
+    w = torch.empty((9, 2 * Cc, wg.shape[2]), dtype=torch.float32, device=wg.device)
+    w[:, rows_g] = kg
+    w[:, rows_b] = kb
+    bias = torch.empty(2 * Cc, dtype=torch.float32, device=wg.device)
+    bias[rows_g] = bg
+    bias[rows_b] = bb
+    return w.contiguous(), bias
+
+
+def conv3x3(ctx: OpContext, x_padded: torch.Tensor, w_kl: torch.Tensor, bias: torch.Tensor, rout: int, stride: int = 1,
+            epilogue: int = EPI_BIAS, aux: Optional[torch.Tensor] = None, aux_shift: int = 0,
+            mean: Optional[torch.Tensor] = None, std: Optional[torch.Tensor] = None, out_padded: bool = False,
+            tile: int = -1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One conv_igemm_f32 launch on torch's current stream.  x_padded [B, rout*stride+2, ., Cin]."""
+    B, Cin = x_padded.shape[0], x_padded.shape[3]
+    N = w_kl.shape[1]
+    Cout = N // 2 if epilogue == EPI_SPADE else N
+    if out is None:
+        shape = (B, rout + 2, rout + 2, Cout) if out_padded else (B, rout, rout, Cout)
+        out = (torch.zeros if out_padded else torch.empty)(shape, dtype=torch.float32, device=x_padded.device)
+    p = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+    rc = ctx.lib.msr_op_conv3x3(ctx.h, x_padded.data_ptr(), w_kl.data_ptr(), bias.data_ptr(), out.data_ptr(), B, rout,
+                                Cin, N, stride, epilogue, p(aux), aux_shift, p(mean), p(std), 1 if out_padded else 0,
+                                tile, torch.cuda.current_stream(x_padded.device).cuda_stream)
+    _lib.raise_for(ctx.lib, ctx.h, rc, "msr_op_conv3x3")
+    return out

@@ -1,0 +1,93 @@
+"""GPU (-m gpu): kernel-level parity of conv_igemm_f32 (all epilogues, both tiles, both strides) against a
+plain PyTorch fp32/fp64 reference of the same op.  Tolerance: rel L-inf <= 1e-5 vs fp64 (fp32 accumulation)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import rel_linf
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(hip_lib):
+    assert torch.cuda.is_available()
+    from moonsuperresolution_amd import ops
+    c = ops.OpContext()
+    yield c
+    c.close()
+
+
+def ref_conv(x, w, b, stride):
+    """TF SAME conv on NHWC in float64 on the CPU."""
+    x, w, b = x.double().cpu(), w.double().cpu(), b.double().cpu()
+    xn = x.permute(0, 3, 1, 2)
+    xn = F.pad(xn, (1, 1, 1, 1)) if stride == 1 else F.pad(xn, (0, 1, 0, 1))
+    return F.conv2d(xn, w.permute(3, 2, 0, 1), b, stride=stride).permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("B,r,cin,cout,stride,tile", [
+    (2, 16, 64, 128, 1, 0), (2, 16, 64, 128, 1, 1), (3, 8, 32, 64, 1, 1), (1, 4, 64, 64, 1, 1),
+    (5, 2, 32, 128, 1, 0), (2, 16, 64, 128, 2, 1), (2, 32, 32, 128, 2, 0), (16, 1, 64, 64, 1, 1),
+    (2, 8, 128, 128, 1, 1 + 256 * 4), (1, 4, 256, 128, 1, 0 + 256 * 8), (2, 16, 64, 64, 2, 1 + 256 * 3)])
+def test_conv_bias(ctx, B, r, cin, cout, stride, tile):
+    from moonsuperresolution_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + r)
+    rin = r * stride
+    x = torch.randn((B, rin, rin, cin), generator=g).cuda()
+    w = (torch.randn((3, 3, cin, cout), generator=g) / np.sqrt(9 * cin)).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    y = ops.conv3x3(ctx, ops.pad_nhwc(x), ops.kernel_layout(w), b, r, stride=stride, tile=tile)
+    assert rel_linf(y.cpu().numpy(), ref_conv(x, w, b, stride).numpy()) <= 1e-5
+
+
+@pytest.mark.parametrize("shift,tile", [(0, 0), (1, 0), (1, 1), (1, 1 + 256 * 2)])
+def test_conv_residual_with_upsample_fold(ctx, shift, tile):
+    from moonsuperresolution_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(7)
+    B, r, cin, cout = 2, 16, 64, 128
+    x = torch.randn((B, r, r, cin), generator=g).cuda()
+    w = (torch.randn((3, 3, cin, cout), generator=g) / 24).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    res = torch.randn((B, r >> shift, r >> shift, cout), generator=g).cuda()
+    y = ops.conv3x3(ctx, ops.pad_nhwc(x), ops.kernel_layout(w), b, r, epilogue=ops.EPI_RES, aux=res, aux_shift=shift,
+                    tile=tile)
+    up = res.double().cpu()
+    if shift:
+        up = up.repeat_interleave(2, 1).repeat_interleave(2, 2)
+    assert rel_linf(y.cpu().numpy(), (ref_conv(x, w, b, 1) + up).numpy()) <= 1e-5
+
+
+@pytest.mark.parametrize("shift,tile,C", [(0, 0, 64), (1, 0, 128), (0, 1, 32), (1, 1 + 256 * 4, 64)])
+def test_conv_spade_epilogue(ctx, shift, tile, C):
+    """gamma/beta as one N=2C GEMM + leaky_relu(gamma * (x-mean)/std + beta) into a zero-bordered tensor."""
+    from moonsuperresolution_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(11)
+    B, r = 2, 16
+    h = torch.relu(torch.randn((B, r, r, 128), generator=g)).cuda()
+    wg = (torch.randn((3, 3, 128, C), generator=g) / 34).cuda()
+    wb = (torch.randn((3, 3, 128, C), generator=g) / 34).cuda()
+    bg, bb = torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+    x = (3 + 2 * torch.randn((B, r >> shift, r >> shift, C), generator=g)).cuda()
+    mean = x.mean((0, 1, 2)).contiguous()
+    std = torch.sqrt(x.var((0, 1, 2), unbiased=False) + 1e-5).contiguous()
+    w, bias = ops.spade_layout(wg, wb, bg, bb)
+    y = ops.conv3x3(ctx, ops.pad_nhwc(h), w, bias, r, epilogue=ops.EPI_SPADE, aux=x, aux_shift=shift, mean=mean,
+                    std=std, out_padded=True, tile=tile)
+    xr = x.double().cpu()
+    if shift:
+        xr = xr.repeat_interleave(2, 1).repeat_interleave(2, 2)
+    v = ref_conv(h, wg, bg, 1) * ((xr - mean.double().cpu()) / std.double().cpu()) + ref_conv(h, wb, bb, 1)
+    v = torch.where(v >= 0, v, 0.2 * v)
+    yc = y.cpu()
+    assert rel_linf(yc[:, 1:-1, 1:-1].numpy(), v.numpy()) <= 1e-5
+    assert float(yc[:, 0].abs().max()) == 0 and float(yc[:, :, -1].abs().max()) == 0     # the border stays zero
+
+
+def test_untileable_shape_is_rejected(ctx):
+    from moonsuperresolution_amd import ops
+    x = torch.zeros((1, 14, 14, 32), device="cuda")       # rout = 12 is not a power of two
+    w = torch.zeros((9, 64, 32), device="cuda")
+    with pytest.raises(ValueError):
+        ops.conv3x3(ctx, x, w, torch.zeros(64, device="cuda"), 12)
