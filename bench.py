@@ -27,7 +27,9 @@ WORKLOADS = {
     "spade256": dict(S=256, B=16, name="SPADE-256 GauGAN(256,16,256) batch=16 256x256 patches (=4 512x512 tiles) per step"),
     "spade512": dict(S=512, B=8, name="SPADE-512 GauGAN(512,8,256) batch=8 512x512 tiles per step"),
 }
-PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (matrix)": v_mfma_f32_32x32x2_f32, dense
+# MI355X_MICROARCH.md: dense MFMA peaks.  For bf16x3 every algorithmic product costs three bf16 MFMA products, so
+# the algorithmic ceiling is a third of the bf16 peak; `achieved` stays ALGORITHMIC FLOP/s in both cases.
+PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0}
 
 
 def host_threads() -> int:
@@ -87,6 +89,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="spade256")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
+                    help="conv arithmetic: exact fp32 MFMA, or 3-term split-bf16 on the bf16 MFMA (fp32 accumulate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     args = ap.parse_args()
@@ -114,7 +118,7 @@ def main():
     S, B = wl["S"], wl["B"]
     weights = make_weights("gaugan", S, seed=1234)
     eps = make_latent_noise(B, 256, seed=7)
-    gen = Generator(S, B, variant="gaugan", weights=weights, eps=eps, device=local)
+    gen = Generator(S, B, variant="gaugan", weights=weights, eps=eps, device=local, precision=args.precision)
     # a small pool of distinct synthetic batches, resident in HBM before the timed region
     pool = [torch.from_numpy(synthetic_patches(B, S, seed=1000 * rank + i)).cuda() for i in range(2)]
     out = torch.empty((B, S, S, 1), dtype=torch.float32, device="cuda")
@@ -152,7 +156,8 @@ def main():
             "metric": "512x512 DEM tiles/s (whole job)", "value": value, "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16x3 (f32 in/out/accumulate)",
+            "data": "synthetic",
             "config": {"workload": wl["name"], "image_size": S, "batch_size": B, "variant": "gaugan",
                        "weights": "random-init (Keras default distributions), seed 1234",
                        "tiles_per_step_per_gpu": tiles_per_step, "parallelism": f"tile-sharded x{world}"},
@@ -163,18 +168,23 @@ def main():
             "achieved_tflops_whole_call": gen.forward_flops() * args.steps / elapsed / 1e12,
             "device_mem_gib": gen.device_bytes() / 2 ** 30,
         }
-        conv = stats.get("conv_igemm_f32")
+        kname = "conv_igemm_f32" if args.precision == "fp32" else "conv_igemm_bf16x3"
+        conv = stats.get(kname)
         if conv and conv["device_ms"] > 0:
             ach = conv["flops"] / (conv["device_ms"] * 1e-3) / 1e12
-            res["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_f32", "achieved": ach,
-                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+            peak = PEAK_TFLOPS[args.precision]
+            res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach,
+                               "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                "traffic": None, "traffic_unit": "bytes per launch (HBM, PMC)",
                                "launches": conv["launches"],
                                "avg_launch_ms": conv["device_ms"] / conv["launches"],
                                "share_of_device_time": conv["device_ms"] / sum(v["device_ms"] for v in stats.values())}
             res["roofline"]["algorithmic_flops_per_launch"] = conv["flops"] / conv["launches"]
-            pmc = pmc_traffic(args.workload)
-            if pmc:
+            if args.precision == "bf16x3":
+                res["roofline"]["mfma_executed_tflops"] = 3 * ach   # three bf16 MFMA products per algorithmic one
+                res["roofline"]["frac_of_executed_mfma_peak"] = 3 * ach / peak
+            pmc = pmc_traffic(args.workload + ("" if args.precision == "fp32" else "_bf16x3"))
+            if pmc and "conv_igemm_f32" in pmc[0]:
                 res["roofline"]["traffic"] = pmc[0]["conv_igemm_f32"]["hbm_bytes_per_launch"]
                 res["roofline"]["traffic_source"] = "profiles/" + pmc[1]
             res["kernel_ms_per_call"] = {k: v["device_ms"] / args.steps for k, v in stats.items()}

@@ -50,8 +50,14 @@ typedef struct {
     int32_t latent_dim;  /* 256 in every reference script (process_full_tiles.py:28) */
     int32_t variant;     /* msr_variant */
     int32_t device;      /* HIP device ordinal */
-    int32_t flags;       /* reserved, 0 */
+    int32_t flags;       /* MSR_FLAG_* */
 } msr_config;
+
+/* Conv arithmetic.  Default (0): exact fp32 on v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak).
+ * MSR_FLAG_BF16X3: 3-term split-bf16 products (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi) on v_mfma_f32_32x32x16_bf16
+ * with fp32 accumulation: per-product error <= ~3*2^-18, all other arithmetic (moments, normalisation, epilogues,
+ * dense, head) stays fp32.  Inputs, outputs and weights of the C ABI are fp32 either way. */
+#define MSR_FLAG_BF16X3 1
 
 typedef struct msr_handle msr_handle;
 
@@ -140,6 +146,14 @@ int msr_op_conv3x3(msr_handle* h, const float* in_dev, const float* wt_dev, cons
                    int32_t B, int32_t rout, int32_t Cin, int32_t N, int32_t stride, int32_t epilogue,
                    const float* aux_dev, int32_t aux_shift, const float* mean_dev, const float* std_dev,
                    int32_t out_padded, int32_t tile, void* stream);
+/* The same with in_dev / wt_dev holding split-bf16 words (msr_op_split_bf16) and the bf16x3 arithmetic;
+ * out_split != 0 (SPADE epilogue only) writes split-bf16 words too. */
+int msr_op_conv3x3_bf16x3(msr_handle* h, const float* in_dev, const float* wt_dev, const float* bias_dev,
+                          float* out_dev, int32_t B, int32_t rout, int32_t Cin, int32_t N, int32_t stride,
+                          int32_t epilogue, const float* aux_dev, int32_t aux_shift, const float* mean_dev,
+                          const float* std_dev, int32_t out_padded, int32_t out_split, int32_t tile, void* stream);
+/* Elementwise fp32 -> split-bf16 word (hi = bf16_rn(v) in the low half, lo = bf16_rn(v - hi) in the high half). */
+int msr_op_split_bf16(msr_handle* h, const float* in_dev, float* out_dev, int64_t count, void* stream);
 
 /* Debug / per-block parity aid: copy a named workspace tensor of the last msr_forward to a HOST buffer
  * (names: "ws.gen.x0", "ws.gen.rb3.x1", "ws.gen.rb3.out", "ws.enc.mv", ...).  Synchronises the device. */

@@ -17,6 +17,7 @@ MSR_ERR_STATE = -3
 MSR_ERR_NOMEM = -4
 
 VARIANT_IDS = {"gaugan": 0, "gaugan_no_kl": 1, "cnn": 2, "pix2pix": 3}
+PRECISION_FLAGS = {"fp32": 0, "bf16x3": 1}   # msr_config.flags (MSR_FLAG_BF16X3)
 
 
 class MsrConfig(C.Structure):
@@ -51,6 +52,9 @@ SYMBOLS = [
     ("msr_forward_flops", C.c_int, [_P, C.POINTER(C.c_double)]),
     ("msr_op_conv3x3", C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                  _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P]),
+    ("msr_op_conv3x3_bf16x3", C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_int32, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    ("msr_op_split_bf16", C.c_int, [_P, _P, _P, C.c_int64, _P]),
     ("msr_debug_tensor", C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
     ("msr_device_bytes", C.c_int, [_P, C.POINTER(C.c_int64)]),
 ]

@@ -28,7 +28,7 @@ struct WeightSpec {
 enum OpType { OP_CONV, OP_SMALLCIN, OP_MOMENTS, OP_NORMACT, OP_DENSE, OP_LATENT, OP_HEAD, OP_DIRECT };
 enum Family { FAM_CONV = 0, FAM_SMALLCIN, FAM_MOMENTS, FAM_NORMACT, FAM_DENSE, FAM_LATENT, FAM_HEAD, FAM_DIRECT,
               FAM_COUNT };
-const char* kFamilyName[FAM_COUNT] = {"conv_igemm_f32", "conv_smallcin", "moments", "norm_act", "dense",
+const char* kFamilyName[FAM_COUNT] = {"conv_igemm", "conv_smallcin", "moments", "norm_act", "dense",
                                       "latent", "head_up_conv4x4", "conv_direct"};
 
 struct Op {
@@ -53,6 +53,7 @@ struct ProfRec { int fam; hipEvent_t a, b; double flops, bytes; };
 struct msr_handle {
     msr_config cfg{};
     int S = 0, B = 0, L = 0, variant = 0;
+    int prec = 0;                                // PREC_F32 or PREC_BF16X3 (cfg.flags & MSR_FLAG_BF16X3)
     std::string err;
     std::vector<WeightSpec> specs;
     std::map<std::string, int> spec_index;
@@ -226,6 +227,14 @@ void hwio_to_tap_oc_ic(const float* src, float* dst, int taps, int cin, int cout
         }
 }
 
+// weights consumed by conv_igemm under MSR_FLAG_BF16X3 are uploaded as split-bf16 words
+int upload_conv_weight(msr_handle* h, const std::string& key, const float* host, size_t floats) {
+    if (h->prec != PREC_BF16X3) return upload(h, key, host, floats);
+    std::vector<float> t(floats);
+    for (size_t i = 0; i < floats; ++i) t[i] = msr_split_bf16(host[i]);
+    return upload(h, key, t.data(), floats);
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -267,6 +276,7 @@ int msr_create(const msr_config* cfg, msr_handle** out) {
     auto h = std::make_unique<msr_handle>();
     h->cfg = *cfg;
     h->S = S; h->B = B; h->L = cfg->latent_dim; h->variant = cfg->variant;
+    h->prec = (cfg->flags & MSR_FLAG_BF16X3) ? PREC_BF16X3 : PREC_F32;
     build_specs(h.get());
     *out = h.release();
     return MSR_OK;
@@ -393,7 +403,7 @@ int msr_load_weight(msr_handle* h, const char* name_c, const float* host, const 
             std::vector<float>& img = h->host_small[base + ".gb.kernel"];
             img.resize((size_t)9 * 2 * C * cin);
             hwio_to_tap_oc_ic(host, img.data(), 9, cin, C, 2 * C, rowmap.data());
-            HIPCHK(h, hipMemcpy(d, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+            rc = upload_conv_weight(h, base + ".gb.kernel", img.data(), img.size());
         }
     } else if (ends_with(name, ".conv_gamma.bias") || ends_with(name, ".conv_beta.bias")) {
         const bool is_beta = ends_with(name, ".conv_beta.bias");
@@ -408,7 +418,7 @@ int msr_load_weight(msr_handle* h, const char* name_c, const float* host, const 
         const int taps = (int)(s[0] * s[1]), cin = (int)s[2], cout = (int)s[3];
         std::vector<float> t(count);
         hwio_to_tap_oc_ic(host, t.data(), taps, cin, cout, cout, nullptr);
-        rc = upload(h, name, t.data(), count);
+        rc = upload_conv_weight(h, name, t.data(), count);
     } else {
         rc = upload(h, name, host, count);
     }
@@ -437,7 +447,8 @@ int alloc_padded(msr_handle* h, const std::string& key, int r, int C, Padded* ou
     return dev_alloc(h, key, (size_t)h->B * (r + 2) * (r + 2) * C, true, &out->base);
 }
 
-Op conv_op(const Padded& in, const float* wt, const float* bias, int B, int rout, int N, int stride, int epi) {
+Op conv_op(const Padded& in, const float* wt, const float* bias, int B, int rout, int N, int stride, int epi,
+           int prec = PREC_F32) {
     Op op; op.type = OP_CONV; op.epi = epi;
     ConvParams& c = op.conv;
     c.in = stride == 1 ? in.base : in.base + in.interior();
@@ -446,7 +457,9 @@ Op conv_op(const Padded& in, const float* wt, const float* bias, int B, int rout
     c.KH = 3; c.KW = 3; c.stride = stride;
     c.in_py = in.py(); c.in_pb = in.pb();
     c.slope = 0.2f;
-    op.tile = conv_pick_tile(B * rout * rout, N, epi);
+    c.prec = prec;
+    c.out_split = (epi == EPI_SPADE && prec == PREC_BF16X3) ? 1 : 0;   // a SPADE output always feeds a conv
+    op.tile = conv_pick_tile(B * rout * rout, N, epi, prec);
     c.ksplit = conv_pick_ksplit(B * rout * rout, N, 9 * (in.C / 32), op.tile);
     c.partial = nullptr;   // bound to the handle's workspace at launch
     op.flops = 2.0 * B * rout * rout * (double)in.C * N * 9;
@@ -489,6 +502,7 @@ int plan_spade(msr_handle* h) {
         p.ay = 2; p.cy = 0; p.lim = S; p.f = 1; p.o = 0;
         p.out_px = 64; p.out_py = e_in.py(); p.out_pb = e_in.pb(); p.out_off = e_in.interior();
         p.act = 2; p.slope = 0.2f;
+        p.out_split = h->prec == PREC_BF16X3;
         op.flops = 2.0 * B * (S / 2) * (S / 2) * 18.0 * 64;
         h->ops.push_back(op);
     }
@@ -502,7 +516,7 @@ int plan_spade(msr_handle* h) {
         snprintf(n, sizeof n, "ws.enc.std%d", i); rc = dev_alloc(h, n, (size_t)B * c, false, &stdv); if (rc) return rc;
         float* zero_bias; rc = dev_alloc(h, "ws.zero_bias", 2048, true, &zero_bias); if (rc) return rc;
         snprintf(n, sizeof n, "enc.ds%d.kernel", i);
-        Op cv = conv_op(e_in, need(n), zero_bias, B, r, c, 2, EPI_BIAS);
+        Op cv = conv_op(e_in, need(n), zero_bias, B, r, c, 2, EPI_BIAS, h->prec);
         set_out_dense(cv.conv, raw, r, c);
         h->ops.push_back(cv);
         h->ops.push_back(moments_op(raw, B, r * r, c, 1e-3f, mean, stdv));
@@ -516,6 +530,7 @@ int plan_spade(msr_handle* h) {
             Padded nx;
             snprintf(n, sizeof n, "ws.enc.p%d", i); rc = alloc_padded(h, n, r, c, &nx); if (rc) return rc;
             na.na.out = nx.base; na.na.out_px = c; na.na.out_py = nx.py(); na.na.out_pb = nx.pb(); na.na.out_off = nx.interior();
+            na.na.out_split = h->prec == PREC_BF16X3;
             e_in = nx;
         } else {
             rc = dev_alloc(h, "ws.enc.flat", (size_t)B * r * r * c, false, &flat); if (rc) return rc;
@@ -586,18 +601,19 @@ int plan_spade(msr_handle* h) {
             p.ay = 1; p.cy = -1; p.lim = r; p.f = S / r; p.o = (S / r) / 2;
             p.out_px = 128; p.out_py = hb.py(); p.out_pb = hb.pb(); p.out_off = hb.interior();
             p.act = 1; p.slope = 0.f;
+            p.out_split = h->prec == PREC_BF16X3;
             em.flops = 2.0 * B * r * r * 18.0 * 128;
             h->ops.push_back(em);
             snprintf(k, sizeof k, "gen.rb%d.spade_%d.gb.kernel", i, j); const float* gbw = need(k);
             snprintf(k, sizeof k, "gen.rb%d.spade_%d.gb.bias", i, j); const float* gbb = need(k);
-            Op gb = conv_op(hb, gbw, gbb, B, r, 2 * C, 1, EPI_SPADE);
+            Op gb = conv_op(hb, gbw, gbb, B, r, 2 * C, 1, EPI_SPADE, h->prec);
             set_out_padded(gb.conv, ab);
             set_aux_dense(gb.conv, x, rx, C, xshift);
             gb.conv.mean = mean; gb.conv.stdv = stdv;
             h->ops.push_back(gb);
             snprintf(k, sizeof k, "gen.rb%d.conv_%d.kernel", i, conv_idx); const float* cw = need(k);
             snprintf(k, sizeof k, "gen.rb%d.conv_%d.bias", i, conv_idx); const float* cb = need(k);
-            Op cv = conv_op(ab, cw, cb, B, r, f, 1, epi);
+            Op cv = conv_op(ab, cw, cb, B, r, f, 1, epi, h->prec);
             set_out_dense(cv.conv, y, r, f);
             if (epi == EPI_RES) set_aux_dense(cv.conv, res, res_r, f, res_shift);
             h->ops.push_back(cv);
@@ -848,10 +864,10 @@ int msr_forward_flops(const msr_handle* hc, double* flops) {
     return MSR_OK;
 }
 
-int msr_op_conv3x3(msr_handle* h, const float* in_dev, const float* wt_dev, const float* bias_dev, float* out_dev,
-                   int32_t B, int32_t rout, int32_t Cin, int32_t N, int32_t stride, int32_t epilogue,
-                   const float* aux_dev, int32_t aux_shift, const float* mean_dev, const float* std_dev,
-                   int32_t out_padded, int32_t tile, void* stream) {
+static int op_conv_impl(msr_handle* h, const float* in_dev, const float* wt_dev, const float* bias_dev, float* out_dev,
+                        int32_t B, int32_t rout, int32_t Cin, int32_t N, int32_t stride, int32_t epilogue,
+                        const float* aux_dev, int32_t aux_shift, const float* mean_dev, const float* std_dev,
+                        int32_t out_padded, int32_t tile, int prec, int out_split, void* stream) {
     if (!h) return MSR_ERR_INVALID;
     if (!in_dev || !wt_dev || !bias_dev || !out_dev || B < 1 || rout < 1 || (stride != 1 && stride != 2))
         return fail(h, MSR_ERR_INVALID, "msr_op_conv3x3: bad argument");
@@ -860,7 +876,8 @@ int msr_op_conv3x3(msr_handle* h, const float* in_dev, const float* wt_dev, cons
         return fail(h, MSR_ERR_INVALID, "msr_op_conv3x3: epilogue %d needs aux / mean / std", epilogue);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     Padded in; in.base = const_cast<float*>(in_dev); in.r = rout * stride; in.C = Cin;
-    Op op = conv_op(in, wt_dev, bias_dev, B, rout, N, stride, epilogue);
+    Op op = conv_op(in, wt_dev, bias_dev, B, rout, N, stride, epilogue, prec);
+    op.conv.out_split = (epilogue == EPI_SPADE && out_split) ? 1 : 0;
     const int Cout = epilogue == EPI_SPADE ? N / 2 : N;
     if (out_padded) { Padded o; o.base = out_dev; o.r = rout; o.C = Cout; set_out_padded(op.conv, o); }
     else set_out_dense(op.conv, out_dev, rout, Cout);
@@ -877,6 +894,30 @@ int msr_op_conv3x3(msr_handle* h, const float* in_dev, const float* wt_dev, cons
     }
     hipError_t e = launch_conv_igemm(op.conv, epilogue, op.tile, (hipStream_t)stream);
     if (e != hipSuccess) return fail(h, MSR_ERR_INVALID, "conv launch rejected (shape not tileable?): %s", hipGetErrorString(e));
+    return MSR_OK;
+}
+
+int msr_op_conv3x3(msr_handle* h, const float* in_dev, const float* wt_dev, const float* bias_dev, float* out_dev,
+                   int32_t B, int32_t rout, int32_t Cin, int32_t N, int32_t stride, int32_t epilogue,
+                   const float* aux_dev, int32_t aux_shift, const float* mean_dev, const float* std_dev,
+                   int32_t out_padded, int32_t tile, void* stream) {
+    return op_conv_impl(h, in_dev, wt_dev, bias_dev, out_dev, B, rout, Cin, N, stride, epilogue, aux_dev, aux_shift,
+                        mean_dev, std_dev, out_padded, tile, PREC_F32, 0, stream);
+}
+
+int msr_op_conv3x3_bf16x3(msr_handle* h, const float* in_dev, const float* wt_dev, const float* bias_dev,
+                          float* out_dev, int32_t B, int32_t rout, int32_t Cin, int32_t N, int32_t stride,
+                          int32_t epilogue, const float* aux_dev, int32_t aux_shift, const float* mean_dev,
+                          const float* std_dev, int32_t out_padded, int32_t out_split, int32_t tile, void* stream) {
+    if ((tile & 0xFF) == TILE_128x128_K16) return fail(h, MSR_ERR_INVALID, "the bf16x3 path has no 16-channel K-step tile");
+    return op_conv_impl(h, in_dev, wt_dev, bias_dev, out_dev, B, rout, Cin, N, stride, epilogue, aux_dev, aux_shift,
+                        mean_dev, std_dev, out_padded, tile, PREC_BF16X3, out_split, stream);
+}
+
+int msr_op_split_bf16(msr_handle* h, const float* in_dev, float* out_dev, int64_t count, void* stream) {
+    if (!h || !in_dev || !out_dev || count < 0) return MSR_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, launch_split_bf16(in_dev, out_dev, (long)count, (hipStream_t)stream));
     return MSR_OK;
 }
 
@@ -918,7 +959,9 @@ int msr_profile_read(msr_handle* h, msr_kernel_stat* out, int32_t cap, int32_t* 
     HIPCHK(h, hipDeviceSynchronize());
     msr_kernel_stat st[FAM_COUNT];
     std::memset(st, 0, sizeof st);
-    for (int f = 0; f < FAM_COUNT; ++f) std::snprintf(st[f].name, sizeof st[f].name, "%s", kFamilyName[f]);
+    for (int f = 0; f < FAM_COUNT; ++f)
+        std::snprintf(st[f].name, sizeof st[f].name, "%s%s", kFamilyName[f],
+                      f == FAM_CONV ? (h->prec == PREC_BF16X3 ? "_bf16x3" : "_f32") : "");
     for (auto& r : h->prof) {
         float ms = 0.f;
         HIPCHK(h, hipEventElapsedTime(&ms, r.a, r.b));

@@ -1,4 +1,5 @@
-// conv_igemm_f32 — NHWC implicit-GEMM convolution for gfx950 on v_mfma_f32_32x32x2_f32.
+// conv_igemm — NHWC implicit-GEMM convolution for gfx950: exact fp32 on v_mfma_f32_32x32x2_f32, or 3-term
+// split-bf16 ("bf16x3") on v_mfma_f32_32x32x16_bf16 (see kernels.h ConvPrecision).
 //
 // Replaces the cuDNN/Eigen Conv2D calls behind spade.py:10-11,19-20 (gamma/beta convs, 49.9 % of the
 // generator's FLOPs) and blocks.py:19-20,26,30-34 (ResidualBlock convs, 48.5 %), plus the strided
@@ -20,6 +21,7 @@
 namespace msr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // K-step = BKC channels of one tap; LDS rows are BKC + 4 floats.  Both pitches (36 and 20 floats) put the 16
 // lanes of a ds_read_b128 group on 16 distinct 16-byte slots, i.e. the fragment reads are conflict-free.
@@ -32,15 +34,36 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     return base + (orig >> 3);
 }
 
+// LDS staging store of one 16-byte global item.  fp32: as is.  split-bf16: the four (hi | lo << 16) words are
+// de-interleaved with v_perm_b32 into 4 hi halves (8 bytes) and 4 lo halves (8 bytes, 64 bytes further on), so
+// a fragment read gets 8 consecutive k of one half with a single ds_read_b128.
+template <int PREC>
+__device__ __forceinline__ void stage_store(float* dst, const float4& v) {
+    if constexpr (PREC == PREC_F32) {
+        *reinterpret_cast<float4*>(dst) = v;
+    } else {
+        const unsigned w0 = __float_as_uint(v.x), w1 = __float_as_uint(v.y), w2 = __float_as_uint(v.z),
+                       w3 = __float_as_uint(v.w);
+        uint2 hi, lo;
+        hi.x = __builtin_amdgcn_perm(w1, w0, 0x05040100u);
+        hi.y = __builtin_amdgcn_perm(w3, w2, 0x05040100u);
+        lo.x = __builtin_amdgcn_perm(w1, w0, 0x07060302u);
+        lo.y = __builtin_amdgcn_perm(w3, w2, 0x07060302u);
+        *reinterpret_cast<uint2*>(dst) = hi;
+        *reinterpret_cast<uint2*>(dst + 16) = lo;
+    }
+}
+
 struct TileGeom {
     int th_l, tw_l, tb;            // log2 tile height/width, samples per tile
     int tiles_x, tiles_y, tiles_b, tiles_n;
     int tiles_mn;                  // tiles_x * tiles_y * tiles_b * tiles_n (the grid is ksplit times that)
 };
 
-template <int WM, int WN, int MT, int NT, int BKC, int EPI>
+template <int WM, int WN, int MT, int NT, int BKC, int EPI, int PREC>
 __global__ void __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2, BKC == 16 ? 3 : 2)))
-conv_igemm_f32(const ConvParams p, const TileGeom g) {
+conv_igemm(const ConvParams p, const TileGeom g) {
+    static_assert(PREC == PREC_F32 || BKC == 32, "the split-bf16 path uses the 32-channel K-step");
     constexpr int NTHR = WM * WN * 64;
     constexpr int BM = WM * MT * 32;
     constexpr int BN = WN * NT * 32;
@@ -84,7 +107,8 @@ conv_igemm_f32(const ConvParams p, const TileGeom g) {
         int b = b0 + tbi;
         b = b < p.B ? b : p.B - 1;   // rows past the batch read valid memory and are dropped in the epilogue
         a_goff[q] = b * p.in_pb + (ty0 + ty) * p.stride * p.in_py + (tx0 + tx) * p.stride * p.Cin + seg * 4;
-        a_loff[q] = row * BKP + seg * 4;
+        // fp32: 16 bytes at k = 4*seg.  split-bf16: the 4 hi halves (8 bytes) at 2*seg, the 4 lo halves 64 bytes on
+        a_loff[q] = row * BKP + (PREC == PREC_F32 ? seg * 4 : seg * 2);
     }
     int b_goff[B_ITEMS];
     int b_loff[B_ITEMS];
@@ -93,7 +117,7 @@ conv_igemm_f32(const ConvParams p, const TileGeom g) {
         const int idx = tid + q * NTHR;
         const int row = idx / SEGS, seg = idx % SEGS;
         b_goff[q] = (n0 + row) * p.Cin + seg * 4;
-        b_loff[q] = row * BKP + seg * 4;
+        b_loff[q] = row * BKP + (PREC == PREC_F32 ? seg * 4 : seg * 2);
     }
 
     // ---- fragment read offsets ------------------------------------------------------------------
@@ -190,35 +214,57 @@ conv_igemm_f32(const ConvParams p, const TileGeom g) {
     {                                                                                            \
         float* a_ = As + (buf) * BM * BKP;                                                       \
         float* b_ = Bs + (buf) * BN * BKP;                                                       \
-        *reinterpret_cast<float4*>(a_ + a_loff[0]) = ra0;                                        \
-        *reinterpret_cast<float4*>(a_ + a_loff[1]) = ra1;                                        \
+        stage_store<PREC>(a_ + a_loff[0], ra0);                                                  \
+        stage_store<PREC>(a_ + a_loff[1], ra1);                                                  \
         if constexpr (A_ITEMS == 4) {                                                            \
-            *reinterpret_cast<float4*>(a_ + a_loff[2]) = ra2;                                    \
-            *reinterpret_cast<float4*>(a_ + a_loff[3]) = ra3;                                    \
+            stage_store<PREC>(a_ + a_loff[2], ra2);                                              \
+            stage_store<PREC>(a_ + a_loff[3], ra3);                                              \
         }                                                                                        \
-        *reinterpret_cast<float4*>(b_ + b_loff[0]) = rb0;                                        \
-        *reinterpret_cast<float4*>(b_ + b_loff[1]) = rb1;                                        \
+        stage_store<PREC>(b_ + b_loff[0], rb0);                                                  \
+        stage_store<PREC>(b_ + b_loff[1], rb1);                                                  \
         if constexpr (B_ITEMS == 4) {                                                            \
-            *reinterpret_cast<float4*>(b_ + b_loff[2]) = rb2;                                    \
-            *reinterpret_cast<float4*>(b_ + b_loff[3]) = rb3;                                    \
+            stage_store<PREC>(b_ + b_loff[2], rb2);                                              \
+            stage_store<PREC>(b_ + b_loff[3], rb3);                                              \
         }                                                                                        \
     }
 #define MSR_COMPUTE(buf)                                                                         \
     {                                                                                            \
         const float* a_ = As + (buf) * BM * BKP;                                                 \
         const float* b_ = Bs + (buf) * BN * BKP;                                                 \
-        _Pragma("unroll") for (int kk = 0; kk < BKC / 8; ++kk) {                                 \
-            float4 fa[MT], fb[NT];                                                               \
-            _Pragma("unroll") for (int m = 0; m < MT; ++m)                                       \
-                fa[m] = *reinterpret_cast<const float4*>(a_ + a_frag[m] + kk * 8);               \
-            _Pragma("unroll") for (int n = 0; n < NT; ++n)                                       \
-                fb[n] = *reinterpret_cast<const float4*>(b_ + b_frag[n] + kk * 8);               \
-            _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                      \
+        if constexpr (PREC == PREC_F32) {                                                        \
+            _Pragma("unroll") for (int kk = 0; kk < BKC / 8; ++kk) {                             \
+                float4 fa[MT], fb[NT];                                                           \
+                _Pragma("unroll") for (int m = 0; m < MT; ++m)                                   \
+                    fa[m] = *reinterpret_cast<const float4*>(a_ + a_frag[m] + kk * 8);           \
+                _Pragma("unroll") for (int n = 0; n < NT; ++n)                                   \
+                    fb[n] = *reinterpret_cast<const float4*>(b_ + b_frag[n] + kk * 8);           \
+                _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                  \
+                    _Pragma("unroll") for (int m = 0; m < MT; ++m) {                             \
+                        const float av = s == 0 ? fa[m].x : s == 1 ? fa[m].y : s == 2 ? fa[m].z : fa[m].w; \
+                        _Pragma("unroll") for (int n = 0; n < NT; ++n) {                         \
+                            const float bv = s == 0 ? fb[n].x : s == 1 ? fb[n].y : s == 2 ? fb[n].z : fb[n].w; \
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m][n], 0, 0, 0); \
+                        }                                                                        \
+                    }                                                                            \
+                }                                                                                \
+            }                                                                                    \
+        } else {                                                                                 \
+            /* rows are [32 hi bf16 | 32 lo bf16 | pad]; lane (i, h) takes k = 16*kg + 8*h + {0..7} */ \
+            _Pragma("unroll") for (int kg = 0; kg < 2; ++kg) {                                   \
+                bf16x8 ah[MT], al[MT], bh[NT], bl[NT];                                           \
                 _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                 \
-                    const float av = s == 0 ? fa[m].x : s == 1 ? fa[m].y : s == 2 ? fa[m].z : fa[m].w; \
+                    ah[m] = *reinterpret_cast<const bf16x8*>(a_ + a_frag[m] + kg * 8);           \
+                    al[m] = *reinterpret_cast<const bf16x8*>(a_ + a_frag[m] + kg * 8 + 16);      \
+                }                                                                                \
+                _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                 \
+                    bh[n] = *reinterpret_cast<const bf16x8*>(b_ + b_frag[n] + kg * 8);           \
+                    bl[n] = *reinterpret_cast<const bf16x8*>(b_ + b_frag[n] + kg * 8 + 16);      \
+                }                                                                                \
+                _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                 \
                     _Pragma("unroll") for (int n = 0; n < NT; ++n) {                             \
-                        const float bv = s == 0 ? fb[n].x : s == 1 ? fb[n].y : s == 2 ? fb[n].z : fb[n].w; \
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m][n], 0, 0, 0); \
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0); \
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0); \
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0); \
                     }                                                                            \
                 }                                                                                \
             }                                                                                    \
@@ -303,7 +349,7 @@ conv_igemm_f32(const ConvParams p, const TileGeom g) {
                     const float normalized = (xrow[ccol[j]] - cmean[j]) / cstd[j];
                     float v = gam * normalized + bet;
                     v = v >= 0.f ? v : v * p.slope;
-                    orow[ccol[j]] = v;
+                    orow[ccol[j]] = p.out_split ? msr_split_bf16(v) : v;
                 }
             } else {
                 const float* rrow = nullptr;
@@ -370,6 +416,10 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(const ConvParams p
                 v.w = v.w * ((xv.w - mu.w) / sd.w) + (bsum.w + b1v.w);
                 v.x = v.x >= 0.f ? v.x : v.x * p.slope; v.y = v.y >= 0.f ? v.y : v.y * p.slope;
                 v.z = v.z >= 0.f ? v.z : v.z * p.slope; v.w = v.w >= 0.f ? v.w : v.w * p.slope;
+                if (p.out_split) {
+                    v.x = msr_split_bf16(v.x); v.y = msr_split_bf16(v.y);
+                    v.z = msr_split_bf16(v.z); v.w = msr_split_bf16(v.w);
+                }
             }
         }
         float* o = p.out + (size_t)p.out_off + (size_t)b * p.out_pb + (size_t)y * p.out_py + (size_t)x * p.out_px + c;
@@ -387,26 +437,28 @@ struct TileCfg {
 // TILE_64x64     : 2 waves, K-step 32, 36 KiB LDS -> 4 workgroups per CU (low-resolution layers, with split-K)
 // TILE_128x128_K16: 4 waves, K-step 16, 40 KiB LDS -> 3 workgroups (3 waves / SIMD) per CU
 
-template <int WM, int WN, int MT, int NT, int BKC, int EPI>
+template <int WM, int WN, int MT, int NT, int BKC, int EPI, int PREC>
 static hipError_t set_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<WM, WN, MT, NT, BKC, EPI>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm<WM, WN, MT, NT, BKC, EPI, PREC>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)TileCfg<WM, WN, MT, NT, BKC>::LDS);
 }
 
-template <int WM, int WN, int MT, int NT, int BKC>
+template <int WM, int WN, int MT, int NT, int BKC, int PREC>
 static hipError_t set_attr_all() {
     hipError_t e;
-    if ((e = set_attr<WM, WN, MT, NT, BKC, EPI_BIAS>()) != hipSuccess) return e;
-    if ((e = set_attr<WM, WN, MT, NT, BKC, EPI_RES>()) != hipSuccess) return e;
-    if ((e = set_attr<WM, WN, MT, NT, BKC, EPI_SPADE>()) != hipSuccess) return e;
-    return set_attr<WM, WN, MT, NT, BKC, EPI_PARTIAL>();
+    if ((e = set_attr<WM, WN, MT, NT, BKC, EPI_BIAS, PREC>()) != hipSuccess) return e;
+    if ((e = set_attr<WM, WN, MT, NT, BKC, EPI_RES, PREC>()) != hipSuccess) return e;
+    if ((e = set_attr<WM, WN, MT, NT, BKC, EPI_SPADE, PREC>()) != hipSuccess) return e;
+    return set_attr<WM, WN, MT, NT, BKC, EPI_PARTIAL, PREC>();
 }
 
 hipError_t conv_igemm_init() {
     hipError_t e;
-    if ((e = set_attr_all<2, 2, 2, 2, 32>()) != hipSuccess) return e;
-    if ((e = set_attr_all<2, 1, 1, 2, 32>()) != hipSuccess) return e;
-    return set_attr_all<2, 2, 2, 2, 16>();
+    if ((e = set_attr_all<2, 2, 2, 2, 32, PREC_F32>()) != hipSuccess) return e;
+    if ((e = set_attr_all<2, 1, 1, 2, 32, PREC_F32>()) != hipSuccess) return e;
+    if ((e = set_attr_all<2, 2, 2, 2, 16, PREC_F32>()) != hipSuccess) return e;
+    if ((e = set_attr_all<2, 2, 2, 2, 32, PREC_BF16X3>()) != hipSuccess) return e;
+    return set_attr_all<2, 1, 1, 2, 32, PREC_BF16X3>();
 }
 
 static int ilog2_floor(int v) {
@@ -435,13 +487,14 @@ static bool make_geom(const ConvParams& p, int BM, int BN, int BKC, TileGeom& g)
     return true;
 }
 
-int conv_pick_tile(int M, int N, int epilogue) {
+int conv_pick_tile(int M, int N, int epilogue, int prec) {
     // The big tile needs >= ~2 waves of workgroups per CU to hide its barrier; otherwise take the small one.
     // Measured on MI355X (tests/gpu_conv_bench.py): the 16-channel K-step (3 workgroups per CU) is ~8 % faster
     // than the 32-channel one for the SPADE epilogue (its long epilogue is covered by a third resident
     // workgroup) and ~3 % slower for plain long-K convs.
     const long big_blocks = (long)((M + 127) / 128) * (N / 128);
-    if (N % 128 == 0 && big_blocks >= 512) return epilogue == EPI_SPADE ? TILE_128x128_K16 : TILE_128x128;
+    if (N % 128 == 0 && big_blocks >= 512)
+        return (epilogue == EPI_SPADE && prec == PREC_F32) ? TILE_128x128_K16 : TILE_128x128;
     return TILE_64x64;
 }
 
@@ -456,14 +509,14 @@ int conv_pick_ksplit(int M, int N, int ksteps, int tile) {
     return ks;
 }
 
-template <int WM, int WN, int MT, int NT, int BKC>
+template <int WM, int WN, int MT, int NT, int BKC, int PREC>
 static hipError_t launch_cfg(const ConvParams& p, int epi, hipStream_t s) {
     using C = TileCfg<WM, WN, MT, NT, BKC>;
     TileGeom g;
     if (!make_geom(p, C::BM, C::BN, BKC, g)) return hipErrorInvalidValue;
     if (p.ksplit > 1) {
         if (!p.partial || epi == EPI_PARTIAL) return hipErrorInvalidValue;
-        conv_igemm_f32<WM, WN, MT, NT, BKC, EPI_PARTIAL><<<g.tiles_mn * p.ksplit, C::NTHR, C::LDS, s>>>(p, g);
+        conv_igemm<WM, WN, MT, NT, BKC, EPI_PARTIAL, PREC><<<g.tiles_mn * p.ksplit, C::NTHR, C::LDS, s>>>(p, g);
         const int Cout = epi == EPI_SPADE ? p.N / 2 : p.N;
         long eb = ((long)p.B * p.Hout * p.Wout * (Cout / 4) + 255) / 256;
         if (eb > 4096) eb = 4096;
@@ -475,13 +528,13 @@ static hipError_t launch_cfg(const ConvParams& p, int epi, hipStream_t s) {
     const int grid = g.tiles_mn;
     switch (epi) {
         case EPI_BIAS:
-            conv_igemm_f32<WM, WN, MT, NT, BKC, EPI_BIAS><<<grid, C::NTHR, C::LDS, s>>>(p, g);
+            conv_igemm<WM, WN, MT, NT, BKC, EPI_BIAS, PREC><<<grid, C::NTHR, C::LDS, s>>>(p, g);
             break;
         case EPI_RES:
-            conv_igemm_f32<WM, WN, MT, NT, BKC, EPI_RES><<<grid, C::NTHR, C::LDS, s>>>(p, g);
+            conv_igemm<WM, WN, MT, NT, BKC, EPI_RES, PREC><<<grid, C::NTHR, C::LDS, s>>>(p, g);
             break;
         case EPI_SPADE:
-            conv_igemm_f32<WM, WN, MT, NT, BKC, EPI_SPADE><<<grid, C::NTHR, C::LDS, s>>>(p, g);
+            conv_igemm<WM, WN, MT, NT, BKC, EPI_SPADE, PREC><<<grid, C::NTHR, C::LDS, s>>>(p, g);
             break;
         default:
             return hipErrorInvalidValue;
@@ -490,9 +543,13 @@ static hipError_t launch_cfg(const ConvParams& p, int epi, hipStream_t s) {
 }
 
 hipError_t launch_conv_igemm(const ConvParams& p, int epilogue, int tile, hipStream_t s) {
-    if (tile == TILE_128x128) return launch_cfg<2, 2, 2, 2, 32>(p, epilogue, s);
-    if (tile == TILE_128x128_K16) return launch_cfg<2, 2, 2, 2, 16>(p, epilogue, s);
-    return launch_cfg<2, 1, 1, 2, 32>(p, epilogue, s);
+    if (p.prec == PREC_BF16X3) {
+        if (tile == TILE_64x64) return launch_cfg<2, 1, 1, 2, 32, PREC_BF16X3>(p, epilogue, s);
+        return launch_cfg<2, 2, 2, 2, 32, PREC_BF16X3>(p, epilogue, s);
+    }
+    if (tile == TILE_128x128) return launch_cfg<2, 2, 2, 2, 32, PREC_F32>(p, epilogue, s);
+    if (tile == TILE_128x128_K16) return launch_cfg<2, 2, 2, 2, 16, PREC_F32>(p, epilogue, s);
+    return launch_cfg<2, 1, 1, 2, 32, PREC_F32>(p, epilogue, s);
 }
 
 }  // namespace msr

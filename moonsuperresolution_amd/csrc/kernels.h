@@ -40,14 +40,36 @@ struct ConvParams {
     float slope;                  // leaky-relu slope of EPI_SPADE
     int ksplit;                   // > 1: the K loop is cut into ksplit ranges, one workgroup each (low-res layers)
     float* partial;               // [ksplit][B*Hout*Wout][N] workspace for split-K
+    int prec;                     // PREC_F32: operands are fp32; PREC_BF16X3: operands are split-bf16 words
+    int out_split;                // EPI_SPADE only: write split-bf16 words (the consumer conv runs PREC_BF16X3)
 };
+
+// Split-bf16 operand format ("bf16x3"): a 32-bit word holds hi = bf16_rn(v) in its low half and
+// lo = bf16_rn(v - hi) in its high half, so tensors keep their fp32 addressing.  The conv computes
+// a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: per-product error
+// <= ~3*2^-18 instead of fp32's 2^-24, at 16/3 of the fp32-MFMA rate.
+enum ConvPrecision : int { PREC_F32 = 0, PREC_BF16X3 = 1 };
+
+__host__ __device__ inline unsigned msr_bf16_rn(float v) {   // round-to-nearest-even, finite inputs
+    union { float f; unsigned u; } c;
+    c.f = v;
+    return (c.u + 0x7FFFu + ((c.u >> 16) & 1u)) >> 16;
+}
+__host__ __device__ inline float msr_split_bf16(float v) {
+    union { float f; unsigned u; } c;
+    const unsigned hi = msr_bf16_rn(v);
+    c.u = hi << 16;
+    const unsigned lo = msr_bf16_rn(v - c.f);
+    c.u = hi | (lo << 16);
+    return c.f;
+}
 
 enum ConvTile : int { TILE_128x128 = 0, TILE_64x64 = 1, TILE_128x128_K16 = 2 };
 
 hipError_t conv_igemm_init();   // sets dynamic-LDS attributes once
 hipError_t launch_conv_igemm(const ConvParams& p, int epilogue, int tile, hipStream_t s);
 // picks the tile and the K split for a problem size (fills the chip for the low-resolution layers)
-int conv_pick_tile(int M, int N, int epilogue);
+int conv_pick_tile(int M, int N, int epilogue, int prec);
 int conv_pick_ksplit(int M, int N, int ksteps, int tile);
 
 // ---------------------------------------------------------------------------------------------
@@ -66,8 +88,10 @@ struct SmallCinParams {
     int out_px, out_py, out_pb, out_off;
     int act;            // 0 none, 1 relu, 2 leaky(slope)
     float slope;
+    int out_split;      // write split-bf16 words for a PREC_BF16X3 consumer
 };
 hipError_t launch_conv_smallcin(const SmallCinParams& p, hipStream_t s);
+hipError_t launch_split_bf16(const float* in, float* out, long n, hipStream_t s);
 
 // Per-group, per-channel moments of x [G, P, C]: mean and sqrt(var_biased + eps) (fp64 accumulation).
 //   G=1 -> tf.nn.moments over (N,H,W) (spade.py:21);  G=B -> tfa InstanceNormalization (blocks.py:63).
@@ -87,6 +111,7 @@ struct NormActParams {
     int B, H, W, C;
     int out_px, out_py, out_pb, out_off;
     float slope;
+    int out_split;        // write split-bf16 words for a PREC_BF16X3 consumer
 };
 hipError_t launch_norm_act(const NormActParams& p, hipStream_t s);
 

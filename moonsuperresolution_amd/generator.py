@@ -33,19 +33,26 @@ class Generator:
         eps: the sampler's N(0,1) draw ``[batch_size, latent_dim]`` for "gaugan"; ``None`` draws a fresh one
             per call like ``tf.random.normal`` (sampling.py:13), an int seeds a fixed one (repeatable runs).
         device: HIP device ordinal (one process per GPU).
+        precision: conv arithmetic — "fp32" (exact fp32 MFMA) or "bf16x3" (3-term split-bf16 products on the
+            bf16 MFMA with fp32 accumulation, ~5e-5 relative L-inf end to end, about twice as fast).  Inputs,
+            outputs, weights and every non-conv op are fp32 either way.
     """
 
     def __init__(self, image_size: int, batch_size: int, latent_dim: int = 256, variant: str = "gaugan",
                  weights: Union[int, Mapping[str, np.ndarray]] = 1234, eps: Union[None, int, np.ndarray] = None,
-                 device: int = 0):
+                 device: int = 0, precision: str = "fp32"):
         if variant not in VARIANTS:
             raise ValueError(f"unknown variant {variant!r}; expected one of {VARIANTS}")
+        if precision not in _lib.PRECISION_FLAGS:
+            raise ValueError(f"unknown precision {precision!r}; expected one of {tuple(_lib.PRECISION_FLAGS)}")
+        self.precision = precision
         self.image_size, self.batch_size, self.latent_dim, self.variant = image_size, batch_size, latent_dim, variant
         self._lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("moonsuperresolution_amd needs a HIP device (MI355X / gfx950); there is no CPU fallback")
         self.device = torch.device("cuda", device)
-        cfg = _lib.MsrConfig(image_size, batch_size, latent_dim, _lib.VARIANT_IDS[variant], device, 0)
+        cfg = _lib.MsrConfig(image_size, batch_size, latent_dim, _lib.VARIANT_IDS[variant], device,
+                             _lib.PRECISION_FLAGS[precision])
         handle = C.c_void_p()
         rc = self._lib.msr_create(C.byref(cfg), C.byref(handle))
         _lib.raise_for(self._lib, None, rc, "msr_create")

@@ -65,11 +65,23 @@ def spade_layout(wg: torch.Tensor, wb: torch.Tensor, bg: torch.Tensor, bb: torch
     return w.contiguous(), bias
 
 
+def split_bf16(ctx: OpContext, x: torch.Tensor) -> torch.Tensor:
+    """fp32 -> split-bf16 words (same shape, float32 storage)."""
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    rc = ctx.lib.msr_op_split_bf16(ctx.h, x.data_ptr(), out.data_ptr(), x.numel(),
+                                   torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.raise_for(ctx.lib, ctx.h, rc, "msr_op_split_bf16")
+    return out
+
+
 def conv3x3(ctx: OpContext, x_padded: torch.Tensor, w_kl: torch.Tensor, bias: torch.Tensor, rout: int, stride: int = 1,
             epilogue: int = EPI_BIAS, aux: Optional[torch.Tensor] = None, aux_shift: int = 0,
             mean: Optional[torch.Tensor] = None, std: Optional[torch.Tensor] = None, out_padded: bool = False,
-            tile: int = -1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """One conv_igemm_f32 launch on torch's current stream.  x_padded [B, rout*stride+2, ., Cin]."""
+            tile: int = -1, out: Optional[torch.Tensor] = None, precision: str = "fp32",
+            out_split: bool = False) -> torch.Tensor:
+    """One conv_igemm launch on torch's current stream.  x_padded [B, rout*stride+2, ., Cin].
+    precision="bf16x3": x_padded and w_kl must already hold split-bf16 words (``split_bf16``)."""
     B, Cin = x_padded.shape[0], x_padded.shape[3]
     N = w_kl.shape[1]
     Cout = N // 2 if epilogue == EPI_SPADE else N
@@ -77,8 +89,14 @@ def conv3x3(ctx: OpContext, x_padded: torch.Tensor, w_kl: torch.Tensor, bias: to
         shape = (B, rout + 2, rout + 2, Cout) if out_padded else (B, rout, rout, Cout)
         out = (torch.zeros if out_padded else torch.empty)(shape, dtype=torch.float32, device=x_padded.device)
     p = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
-    rc = ctx.lib.msr_op_conv3x3(ctx.h, x_padded.data_ptr(), w_kl.data_ptr(), bias.data_ptr(), out.data_ptr(), B, rout,
-                                Cin, N, stride, epilogue, p(aux), aux_shift, p(mean), p(std), 1 if out_padded else 0,
-                                tile, torch.cuda.current_stream(x_padded.device).cuda_stream)
+    stream = torch.cuda.current_stream(x_padded.device).cuda_stream
+    if precision == "bf16x3":
+        rc = ctx.lib.msr_op_conv3x3_bf16x3(ctx.h, x_padded.data_ptr(), w_kl.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                           B, rout, Cin, N, stride, epilogue, p(aux), aux_shift, p(mean), p(std),
+                                           1 if out_padded else 0, 1 if out_split else 0, tile, stream)
+    else:
+        rc = ctx.lib.msr_op_conv3x3(ctx.h, x_padded.data_ptr(), w_kl.data_ptr(), bias.data_ptr(), out.data_ptr(), B,
+                                    rout, Cin, N, stride, epilogue, p(aux), aux_shift, p(mean), p(std),
+                                    1 if out_padded else 0, tile, stream)
     _lib.raise_for(ctx.lib, ctx.h, rc, "msr_op_conv3x3")
     return out

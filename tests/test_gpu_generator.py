@@ -160,3 +160,27 @@ def test_pix2pix_against_oracle(Generator):
     assert np.allclose(y[0, 16::32, 16::32, 0], g["probe"], atol=TOL * g["absmax"])
     assert abs(gen.forward_flops() / 1e9 - 11.929) < 1e-3
     gen.close()
+
+
+def test_bf16x3_precision_within_tolerance(Generator):
+    """MSR_FLAG_BF16X3: conv products as 3-term split-bf16 on the bf16 MFMA; everything else fp32.
+    Same <= 1e-3 bar against the float64 oracle (observed ~1e-4)."""
+    from oracle import generator_ref
+    g = np.load(os.path.join(GOLD, "spade64_gaugan.npz"))
+    w = make_weights("gaugan", 64, seed=1234, bias_scale=0.05)
+    gen = Generator(64, 2, variant="gaugan", weights=w, eps=make_latent_noise(2, 256, 7), precision="bf16x3")
+    y = gen(synthetic_patches(2, 64, 0))
+    assert rel_linf(y, g["output"]) <= TOL
+    gen.close()
+    w = make_weights("gaugan", 256, seed=1234, bias_scale=0.05)
+    eps = make_latent_noise(2, 256, 7)
+    x = synthetic_patches(2, 256, 0)
+    gen = Generator(256, 2, variant="gaugan", weights=w, eps=eps, precision="bf16x3")
+    y = gen(x)
+    ref = generator_ref.spade_call(x, w, "gaugan", eps, dtype=torch.float64)
+    err = rel_linf(y, ref)
+    print("bf16x3 S=256 rel Linf", err)
+    assert err <= TOL
+    gen.close()
+    with pytest.raises(ValueError):
+        Generator(64, 2, precision="fp8")
