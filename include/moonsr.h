@@ -152,7 +152,8 @@ int msr_op_conv3x3_bf16x3(msr_handle* h, const float* in_dev, const float* wt_de
                           float* out_dev, int32_t B, int32_t rout, int32_t Cin, int32_t N, int32_t stride,
                           int32_t epilogue, const float* aux_dev, int32_t aux_shift, const float* mean_dev,
                           const float* std_dev, int32_t out_padded, int32_t out_split, int32_t tile, void* stream);
-/* Elementwise fp32 -> split-bf16 word (hi = bf16_rn(v) in the low half, lo = bf16_rn(v - hi) in the high half). */
+/* fp32 -> split-bf16 image: every aligned group of 32 values (one channel chunk; count % 32 == 0) becomes
+ * [32 x hi bf16 | 32 x lo bf16], hi = bf16_rn(v), lo = bf16_rn(v - hi); size and addressing stay those of fp32. */
 int msr_op_split_bf16(msr_handle* h, const float* in_dev, float* out_dev, int64_t count, void* stream);
 
 /* Debug / per-block parity aid: copy a named workspace tensor of the last msr_forward to a HOST buffer

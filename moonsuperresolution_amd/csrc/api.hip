@@ -227,12 +227,55 @@ void hwio_to_tap_oc_ic(const float* src, float* dst, int taps, int cin, int cout
         }
 }
 
-// weights consumed by conv_igemm under MSR_FLAG_BF16X3 are uploaded as split-bf16 words
-int upload_conv_weight(msr_handle* h, const std::string& key, const float* host, size_t floats) {
+// Weights consumed by conv_igemm_bf16x3 are uploaded in MFMA-fragment order (conv_igemm.hip):
+//   [tap][chunk of 32 k][n-tile of 32][kg][hi|lo][lane = 32*h + j][8 bf16],  value = W[tap][32*nt + j][32*cc + 16*kg + 8*h + e]
+// `host` is the kernel layout [taps][N][Cin].
+int upload_conv_weight(msr_handle* h, const std::string& key, const float* host, size_t floats, int taps, int N,
+                       int Cin, bool frag) {
     if (h->prec != PREC_BF16X3) return upload(h, key, host, floats);
+    if (N % 32 || Cin % 32 || (size_t)taps * N * Cin != floats)
+        return fail(h, MSR_ERR_INVALID, "%s: bf16x3 needs Cin and Cout multiples of 32", key.c_str());
     std::vector<float> t(floats);
-    for (size_t i = 0; i < floats; ++i) t[i] = msr_split_bf16(host[i]);
+    if (!frag) {
+        // split-bf16 image of [tap][N][Cin]: every 32 consecutive k become [32 hi | 32 lo]
+        for (size_t i = 0; i + 3 < floats; i += 4)
+            msr_store_split4(t.data() + (i & ~(size_t)31), (int)(i & 31), host[i], host[i + 1], host[i + 2], host[i + 3]);
+        return upload(h, key, t.data(), floats);
+    }
+    uint16_t* o = reinterpret_cast<uint16_t*>(t.data());
+    const int chunks = Cin / 32, nt32 = N / 32;
+    for (int tap = 0; tap < taps; ++tap)
+        for (int cc = 0; cc < chunks; ++cc)
+            for (int nt = 0; nt < nt32; ++nt) {
+                uint16_t* blk = o + (((size_t)tap * chunks + cc) * nt32 + nt) * 2048;   // 1024 floats
+                for (int kg = 0; kg < 2; ++kg)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int j = lane & 31, hh = lane >> 5;
+                        const float* src = host + ((size_t)tap * N + nt * 32 + j) * Cin + cc * 32 + kg * 16 + hh * 8;
+                        uint16_t* hi = blk + ((kg * 2 + 0) * 64 + lane) * 8;
+                        uint16_t* lo = blk + ((kg * 2 + 1) * 64 + lane) * 8;
+                        for (int e = 0; e < 8; ++e) {
+                            unsigned a, b2;
+                            msr_split_bf16(src[e], a, b2);
+                            hi[e] = (uint16_t)a; lo[e] = (uint16_t)b2;
+                        }
+                    }
+            }
     return upload(h, key, t.data(), floats);
+}
+
+struct ConvVariant { int tile; int wt_frag; };
+ConvVariant pick_conv_variant(int B, int rout, int N, int stride, int epi, int prec);
+
+// Output resolution of the conv a weight belongs to ("enc.ds3.kernel" -> S>>3, "gen.rb4...." -> sw<<3).
+bool weight_uses_frag(msr_handle* h, const std::string& name, int N, int epi) {
+    if (h->prec != PREC_BF16X3) return false;
+    int rout = 0, stride = 1;
+    int i = 0;
+    if (std::sscanf(name.c_str(), "enc.ds%d.", &i) == 1) { rout = h->S >> i; stride = 2; }
+    else if (std::sscanf(name.c_str(), "gen.rb%d.", &i) == 1) rout = (h->S / 64) << (i - 1);
+    else return false;
+    return pick_conv_variant(h->B, rout, N, stride, epi, h->prec).wt_frag != 0;
 }
 
 }  // namespace
@@ -403,7 +446,8 @@ int msr_load_weight(msr_handle* h, const char* name_c, const float* host, const 
             std::vector<float>& img = h->host_small[base + ".gb.kernel"];
             img.resize((size_t)9 * 2 * C * cin);
             hwio_to_tap_oc_ic(host, img.data(), 9, cin, C, 2 * C, rowmap.data());
-            rc = upload_conv_weight(h, base + ".gb.kernel", img.data(), img.size());
+            rc = upload_conv_weight(h, base + ".gb.kernel", img.data(), img.size(), 9, 2 * C, cin,
+                                    weight_uses_frag(h, name, 2 * C, EPI_SPADE));
         }
     } else if (ends_with(name, ".conv_gamma.bias") || ends_with(name, ".conv_beta.bias")) {
         const bool is_beta = ends_with(name, ".conv_beta.bias");
@@ -418,7 +462,7 @@ int msr_load_weight(msr_handle* h, const char* name_c, const float* host, const 
         const int taps = (int)(s[0] * s[1]), cin = (int)s[2], cout = (int)s[3];
         std::vector<float> t(count);
         hwio_to_tap_oc_ic(host, t.data(), taps, cin, cout, cout, nullptr);
-        rc = upload_conv_weight(h, name, t.data(), count);
+        rc = upload_conv_weight(h, name, t.data(), count, taps, cout, cin, weight_uses_frag(h, name, cout, EPI_BIAS));
     } else {
         rc = upload(h, name, host, count);
     }
@@ -447,6 +491,19 @@ int alloc_padded(msr_handle* h, const std::string& key, int r, int C, Padded* ou
     return dev_alloc(h, key, (size_t)h->B * (r + 2) * (r + 2) * C, true, &out->base);
 }
 
+// Kernel variant of one conv layer.  Under bf16x3 it also fixes the weight layout, so msr_load_weight and the
+// planner must agree: both call this.
+ConvVariant pick_conv_variant(int B, int rout, int N, int stride, int epi, int prec) {
+    ConvVariant v;
+    v.tile = conv_pick_tile(B * rout * rout, N, epi, prec);
+    v.wt_frag = 0;
+    if (prec == PREC_BF16X3) {
+        if (v.tile == TILE_64x64) v.wt_frag = 1;                          // B in VGPRs: +18 % on the small tile
+        else if (stride == 1 && rout >= 16) v.tile = TILE_128x128_HALO;   // LDS-staged input halo
+    }
+    return v;
+}
+
 Op conv_op(const Padded& in, const float* wt, const float* bias, int B, int rout, int N, int stride, int epi,
            int prec = PREC_F32) {
     Op op; op.type = OP_CONV; op.epi = epi;
@@ -459,8 +516,10 @@ Op conv_op(const Padded& in, const float* wt, const float* bias, int B, int rout
     c.slope = 0.2f;
     c.prec = prec;
     c.out_split = (epi == EPI_SPADE && prec == PREC_BF16X3) ? 1 : 0;   // a SPADE output always feeds a conv
-    op.tile = conv_pick_tile(B * rout * rout, N, epi, prec);
-    c.ksplit = conv_pick_ksplit(B * rout * rout, N, 9 * (in.C / 32), op.tile);
+    const ConvVariant cv = pick_conv_variant(B, rout, N, stride, epi, prec);
+    op.tile = cv.tile;
+    c.wt_frag = cv.wt_frag;
+    c.ksplit = op.tile == TILE_128x128_HALO ? 1 : conv_pick_ksplit(B * rout * rout, N, 9 * (in.C / 32), op.tile);
     c.partial = nullptr;   // bound to the handle's workspace at launch
     op.flops = 2.0 * B * rout * rout * (double)in.C * N * 9;
     return op;
@@ -884,7 +943,8 @@ static int op_conv_impl(msr_handle* h, const float* in_dev, const float* wt_dev,
     if (epilogue != EPI_BIAS) set_aux_dense(op.conv, aux_dev, rout >> aux_shift, Cout, aux_shift);
     op.conv.mean = mean_dev; op.conv.stdv = std_dev;
     if (tile >= 0) {
-        op.tile = tile & 0xFF;
+        op.tile = tile & 0x3F;
+        op.conv.wt_frag = (tile & 0x40) ? 1 : 0;
         op.conv.ksplit = (tile >> 8) > 0 ? (tile >> 8) : 1;    // explicit tile: explicit split (default none)
     }
     if (op.conv.ksplit > 1) {
@@ -909,13 +969,15 @@ int msr_op_conv3x3_bf16x3(msr_handle* h, const float* in_dev, const float* wt_de
                           float* out_dev, int32_t B, int32_t rout, int32_t Cin, int32_t N, int32_t stride,
                           int32_t epilogue, const float* aux_dev, int32_t aux_shift, const float* mean_dev,
                           const float* std_dev, int32_t out_padded, int32_t out_split, int32_t tile, void* stream) {
-    if ((tile & 0xFF) == TILE_128x128_K16) return fail(h, MSR_ERR_INVALID, "the bf16x3 path has no 16-channel K-step tile");
+    if (tile < 0) return fail(h, MSR_ERR_INVALID, "msr_op_conv3x3_bf16x3 needs an explicit tile (the weight layout depends on it)");
+    if ((tile & 0x3F) == TILE_128x128_K16) return fail(h, MSR_ERR_INVALID, "the bf16x3 path has no 16-channel K-step tile");
     return op_conv_impl(h, in_dev, wt_dev, bias_dev, out_dev, B, rout, Cin, N, stride, epilogue, aux_dev, aux_shift,
                         mean_dev, std_dev, out_padded, tile, PREC_BF16X3, out_split, stream);
 }
 
 int msr_op_split_bf16(msr_handle* h, const float* in_dev, float* out_dev, int64_t count, void* stream) {
     if (!h || !in_dev || !out_dev || count < 0) return MSR_ERR_INVALID;
+    if (count % 32) return fail(h, MSR_ERR_INVALID, "msr_op_split_bf16: count must be a multiple of 32 (channel chunks)");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, launch_split_bf16(in_dev, out_dev, (long)count, (hipStream_t)stream));
     return MSR_OK;

@@ -34,24 +34,11 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     return base + (orig >> 3);
 }
 
-// LDS staging store of one 16-byte global item.  fp32: as is.  split-bf16: the four (hi | lo << 16) words are
-// de-interleaved with v_perm_b32 into 4 hi halves (8 bytes) and 4 lo halves (8 bytes, 64 bytes further on), so
-// a fragment read gets 8 consecutive k of one half with a single ds_read_b128.
+// LDS staging store of one 16-byte global item: a plain copy for both precisions (split-bf16 tensors already hold
+// the [32 hi | 32 lo] chunk image in HBM, see kernels.h).
 template <int PREC>
 __device__ __forceinline__ void stage_store(float* dst, const float4& v) {
-    if constexpr (PREC == PREC_F32) {
-        *reinterpret_cast<float4*>(dst) = v;
-    } else {
-        const unsigned w0 = __float_as_uint(v.x), w1 = __float_as_uint(v.y), w2 = __float_as_uint(v.z),
-                       w3 = __float_as_uint(v.w);
-        uint2 hi, lo;
-        hi.x = __builtin_amdgcn_perm(w1, w0, 0x05040100u);
-        hi.y = __builtin_amdgcn_perm(w3, w2, 0x05040100u);
-        lo.x = __builtin_amdgcn_perm(w1, w0, 0x07060302u);
-        lo.y = __builtin_amdgcn_perm(w3, w2, 0x07060302u);
-        *reinterpret_cast<uint2*>(dst) = hi;
-        *reinterpret_cast<uint2*>(dst + 16) = lo;
-    }
+    *reinterpret_cast<float4*>(dst) = v;
 }
 
 struct TileGeom {
@@ -59,6 +46,100 @@ struct TileGeom {
     int tiles_x, tiles_y, tiles_b, tiles_n;
     int tiles_mn;                  // tiles_x * tiles_y * tiles_b * tiles_n (the grid is ksplit times that)
 };
+
+// ------------------------------------------------------------------------------------------------------
+// Epilogue shared by the fp32 and the split-bf16 kernels.
+// ------------------------------------------------------------------------------------------------------
+template <int WM, int WN, int MT, int NT, int EPI>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileGeom& g, f32x16 (&acc)[MT][NT], int ks,
+                                              int wm, int wn, int half, int l31, int n0, int tx0, int ty0, int b0) {
+    const int twm = (1 << g.tw_l) - 1, thm = (1 << g.th_l) - 1;
+    // ---- epilogue -----------------------------------------------------------------------------------
+    // C/D map of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
+    // Per-column constants (bias, SPADE mean / std) are loaded once, before the row loops.
+    if constexpr (EPI == EPI_PARTIAL) {
+        float* pbase = p.partial + (size_t)ks * ((size_t)p.B * p.Hout * p.Wout * p.N);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int tx = row & twm, ty = (row >> g.tw_l) & thm, tbi = row >> (g.tw_l + g.th_l);
+                const int bb = b0 + tbi;
+                if (tbi >= g.tb || bb >= p.B) continue;
+                float* orow = pbase + (((size_t)bb * p.Hout + ty0 + ty) * p.Wout + tx0 + tx) * p.N;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) orow[n0 + (wn * NT + n) * 32 + l31] = acc[m][n][r];
+            }
+        }
+        return;
+    }
+    constexpr int NCH = EPI == EPI_SPADE ? NT / 2 : NT;
+    float cb0[NCH], cb1[NCH], cmean[NCH], cstd[NCH];
+    int ccol[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        if constexpr (EPI == EPI_SPADE) {
+            const int colg = n0 + (wn * NT + 2 * j) * 32 + l31;   // gamma column; its beta twin is +32
+            ccol[j] = (n0 + wn * NT * 32) / 2 + j * 32 + l31;    // channel
+            cb0[j] = p.bias[colg];
+            cb1[j] = p.bias[colg + 32];
+            cmean[j] = p.mean[ccol[j]];
+            cstd[j] = p.stdv[ccol[j]];
+        } else {
+            ccol[j] = n0 + (wn * NT + j) * 32 + l31;
+            cb0[j] = p.bias[ccol[j]];
+            cb1[j] = cmean[j] = cstd[j] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int tx = row & twm, ty = (row >> g.tw_l) & thm, tbi = row >> (g.tw_l + g.th_l);
+            const int bb = b0 + tbi;
+            if (tbi >= g.tb || bb >= p.B) continue;
+            const int y = ty0 + ty, x = tx0 + tx;
+            float* orow = p.out + (size_t)p.out_off + (size_t)bb * p.out_pb + y * p.out_py + x * p.out_px;
+            if constexpr (EPI == EPI_SPADE) {
+                const float* xrow = p.aux + (size_t)bb * p.aux_pb + (y >> p.aux_shift) * p.aux_py +
+                                    (x >> p.aux_shift) * p.aux_px;
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
+                    const float gam = acc[m][2 * j][r] + cb0[j];
+                    const float bet = acc[m][2 * j + 1][r] + cb1[j];
+                    const float normalized = (xrow[ccol[j]] - cmean[j]) / cstd[j];
+                    float v = gam * normalized + bet;
+                    v = v >= 0.f ? v : v * p.slope;
+                    if (p.out_split) {
+                        // lanes 0..31 of a half-wave hold the 32 channels of ONE chunk of this pixel: pair up
+                        // neighbouring lanes so that every lane still issues one 4-byte store
+                        unsigned hi, lo;
+                        msr_split_bf16(v, hi, lo);
+                        const unsigned nhi = __shfl_xor(hi, 1), nlo = __shfl_xor(lo, 1);
+                        unsigned* chunk = reinterpret_cast<unsigned*>(orow) + (ccol[j] & ~31);
+                        if (l31 & 1) chunk[16 + (l31 >> 1)] = nlo | (lo << 16);
+                        else chunk[l31 >> 1] = hi | (nhi << 16);
+                    } else {
+                        orow[ccol[j]] = v;
+                    }
+                }
+            } else {
+                const float* rrow = nullptr;
+                if constexpr (EPI == EPI_RES)
+                    rrow = p.aux + (size_t)bb * p.aux_pb + (y >> p.aux_shift) * p.aux_py +
+                           (x >> p.aux_shift) * p.aux_px;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    float v = acc[m][n][r] + cb0[n];
+                    if constexpr (EPI == EPI_RES) v += rrow[ccol[n]];
+                    orow[ccol[n]] = v;
+                }
+            }
+        }
+    }
+}
 
 template <int WM, int WN, int MT, int NT, int BKC, int EPI, int PREC>
 __global__ void __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2, BKC == 16 ? 3 : 2)))
@@ -107,8 +188,7 @@ conv_igemm(const ConvParams p, const TileGeom g) {
         int b = b0 + tbi;
         b = b < p.B ? b : p.B - 1;   // rows past the batch read valid memory and are dropped in the epilogue
         a_goff[q] = b * p.in_pb + (ty0 + ty) * p.stride * p.in_py + (tx0 + tx) * p.stride * p.Cin + seg * 4;
-        // fp32: 16 bytes at k = 4*seg.  split-bf16: the 4 hi halves (8 bytes) at 2*seg, the 4 lo halves 64 bytes on
-        a_loff[q] = row * BKP + (PREC == PREC_F32 ? seg * 4 : seg * 2);
+        a_loff[q] = row * BKP + seg * 4;
     }
     int b_goff[B_ITEMS];
     int b_loff[B_ITEMS];
@@ -117,7 +197,7 @@ conv_igemm(const ConvParams p, const TileGeom g) {
         const int idx = tid + q * NTHR;
         const int row = idx / SEGS, seg = idx % SEGS;
         b_goff[q] = (n0 + row) * p.Cin + seg * 4;
-        b_loff[q] = row * BKP + (PREC == PREC_F32 ? seg * 4 : seg * 2);
+        b_loff[q] = row * BKP + seg * 4;
     }
 
     // ---- fragment read offsets ------------------------------------------------------------------
@@ -291,80 +371,383 @@ conv_igemm(const ConvParams p, const TileGeom g) {
 #undef MSR_WRITE_LDS
 #undef MSR_COMPUTE
 
-    // ---- epilogue -----------------------------------------------------------------------------------
-    // C/D map of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
-    // Per-column constants (bias, SPADE mean / std) are loaded once, before the row loops.
-    if constexpr (EPI == EPI_PARTIAL) {
-        float* pbase = p.partial + (size_t)ks * ((size_t)p.B * p.Hout * p.Wout * p.N);
+    conv_epilogue<WM, WN, MT, NT, EPI>(p, g, acc, ks, wm, wn, half, l31, n0, tx0, ty0, b0);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// conv_igemm_bf16x3: the split-bf16 kernel with the WEIGHT operand kept out of LDS.
+//
+// At bf16 MFMA rates the 128x128 tile is LDS-bound (staging writes + fragment reads of both operands use ~85 % of
+// the LDS), so the weights are stored in HBM in MFMA-fragment order,
+//     wt[tap][chunk][n-tile of 32][kg][hi|lo][lane 0..63][8 bf16]          (1 KiB per wave-instruction)
+// and every wave loads its own B fragments straight into VGPRs with coalesced global_load_dwordx4, one K-step
+// ahead (two named register sets, the loop is unrolled by two).  Only the activation tile goes through LDS
+// (global -> VGPR -> LDS, double-buffered, one barrier per K-step, as in the fp32 kernel).
+// ------------------------------------------------------------------------------------------------------
+template <int WM, int WN, int MT, int NT, int EPI>
+__global__ void __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+conv_igemm_bf16x3(const ConvParams p, const TileGeom g) {
+    static_assert(NT == 2, "B register sets are written for two n-tiles per wave");
+    constexpr int NTHR = WM * WN * 64;
+    constexpr int BM = WM * MT * 32;
+    constexpr int BN = WN * NT * 32;
+    constexpr int BKC = 32, BKP = 36, SEGS = 8;
+    constexpr int A_ITEMS = BM * SEGS / NTHR;
+    static_assert(A_ITEMS == 4, "staging is written for 4 16-byte items per thread");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const As = smem;                      // [2][BM][BKP]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int bid_all = xcd_remap(blockIdx.x, gridDim.x);
+    const int ks = bid_all / g.tiles_mn;
+    const int bid = bid_all - ks * g.tiles_mn;
+    const int tn = bid % g.tiles_n;
+    int tmi = bid / g.tiles_n;
+    const int tx0 = (tmi % g.tiles_x) << g.tw_l;
+    tmi /= g.tiles_x;
+    const int ty0 = (tmi % g.tiles_y) << g.th_l;
+    const int b0 = (tmi / g.tiles_y) * g.tb;
+    const int n0 = tn * BN;
+    const int twm = (1 << g.tw_l) - 1, thm = (1 << g.th_l) - 1;
+
+    int a_goff[A_ITEMS], a_loff[A_ITEMS];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int tx = row & twm, ty = (row >> g.tw_l) & thm, tbi = row >> (g.tw_l + g.th_l);
-                const int bb = b0 + tbi;
-                if (tbi >= g.tb || bb >= p.B) continue;
-                float* orow = pbase + (((size_t)bb * p.Hout + ty0 + ty) * p.Wout + tx0 + tx) * p.N;
-#pragma unroll
-                for (int n = 0; n < NT; ++n) orow[n0 + (wn * NT + n) * 32 + l31] = acc[m][n][r];
-            }
-        }
-        return;
+    for (int q = 0; q < A_ITEMS; ++q) {
+        const int idx = tid + q * NTHR;
+        const int row = idx / SEGS, seg = idx % SEGS;
+        const int tx = row & twm, ty = (row >> g.tw_l) & thm, tbi = row >> (g.tw_l + g.th_l);
+        int b = b0 + tbi;
+        b = b < p.B ? b : p.B - 1;
+        a_goff[q] = b * p.in_pb + (ty0 + ty) * p.stride * p.in_py + (tx0 + tx) * p.stride * p.Cin + seg * 4;
+        a_loff[q] = row * BKP + seg * 4;
     }
-    constexpr int NCH = EPI == EPI_SPADE ? NT / 2 : NT;
-    float cb0[NCH], cb1[NCH], cmean[NCH], cstd[NCH];
-    int ccol[NCH];
+    int a_frag[MT];
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        if constexpr (EPI == EPI_SPADE) {
-            const int colg = n0 + (wn * NT + 2 * j) * 32 + l31;   // gamma column; its beta twin is +32
-            ccol[j] = (n0 + wn * NT * 32) / 2 + j * 32 + l31;    // channel
-            cb0[j] = p.bias[colg];
-            cb1[j] = p.bias[colg + 32];
-            cmean[j] = p.mean[ccol[j]];
-            cstd[j] = p.stdv[ccol[j]];
-        } else {
-            ccol[j] = n0 + (wn * NT + j) * 32 + l31;
-            cb0[j] = p.bias[ccol[j]];
-            cb1[j] = cmean[j] = cstd[j] = 0.f;
-        }
+    for (int m = 0; m < MT; ++m) a_frag[m] = ((wm * MT + m) * 32 + l31) * BKP + 4 * half;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const int taps = p.KH * p.KW;
+    const int chunks = p.Cin / BKC;
+    const int steps = taps * chunks;
+    const int nt32 = p.N / 32;
+    // fragment-order weights: 1024 floats per (tap, chunk, n-tile): [kg][hi|lo][lane][4 floats]
+    const size_t w_chunk_stride = (size_t)nt32 * 1024;           // next channel chunk, same tap
+    const size_t w_tap_stride = (size_t)chunks * w_chunk_stride;  // next tap, same chunk
+
+    const int t_begin = (int)((long)ks * steps / p.ksplit), t_end = (int)((long)(ks + 1) * steps / p.ksplit);
+    const int cc0 = t_begin / taps, tap0 = t_begin - cc0 * taps;
+    int it_kh = tap0 / p.KW, it_kw = tap0 - it_kh * p.KW;
+    const float* a_src = p.in + (it_kh * p.in_py + it_kw * p.Cin + cc0 * BKC);
+    const float* b_src = p.wt + (size_t)tap0 * w_tap_stride + (size_t)cc0 * w_chunk_stride +
+                         (size_t)(n0 / 32 + wn * NT) * 1024 + lane * 4;
+
+    float4 ra0, ra1, ra2, ra3;
+    // B fragments of one K-step: [n-tile 0/1][kg 0/1][hi/lo]; two sets P (even steps) and Q (odd steps)
+    bf16x8 P00h, P00l, P01h, P01l, P10h, P10l, P11h, P11l;
+    bf16x8 Q00h, Q00l, Q01h, Q01l, Q10h, Q10l, Q11h, Q11l;
+
+#define MSR_LDB(ptr, off) (*reinterpret_cast<const bf16x8*>((ptr) + (off)))
+#define MSR_LOAD_B(S)                                                                            \
+    {                                                                                            \
+        S##00h = MSR_LDB(b_src, 0);        S##00l = MSR_LDB(b_src, 256);                         \
+        S##01h = MSR_LDB(b_src, 512);      S##01l = MSR_LDB(b_src, 768);                         \
+        S##10h = MSR_LDB(b_src, 1024);     S##10l = MSR_LDB(b_src, 1280);                        \
+        S##11h = MSR_LDB(b_src, 1536);     S##11l = MSR_LDB(b_src, 1792);                        \
     }
+#define MSR_LOAD_A()                                                                             \
+    {                                                                                            \
+        ra0 = *reinterpret_cast<const float4*>(a_src + a_goff[0]);                               \
+        ra1 = *reinterpret_cast<const float4*>(a_src + a_goff[1]);                               \
+        ra2 = *reinterpret_cast<const float4*>(a_src + a_goff[2]);                               \
+        ra3 = *reinterpret_cast<const float4*>(a_src + a_goff[3]);                               \
+    }
+#define MSR_ADVANCE()                                                                            \
+    {                                                                                            \
+        ++it_kw;                                                                                 \
+        a_src += p.Cin;                                                                          \
+        b_src += w_tap_stride;                                                                   \
+        if (it_kw == p.KW) {                                                                     \
+            it_kw = 0;                                                                           \
+            ++it_kh;                                                                             \
+            a_src += p.in_py - p.KW * p.Cin;                                                     \
+            if (it_kh == p.KH) {                                                                 \
+                it_kh = 0;                                                                       \
+                a_src += BKC - p.KH * p.in_py;                                                   \
+                b_src += w_chunk_stride - (size_t)taps * w_tap_stride;                           \
+            }                                                                                    \
+        }                                                                                        \
+    }
+#define MSR_WRITE_A(buf)                                                                         \
+    {                                                                                            \
+        float* a_ = As + (buf) * BM * BKP;                                                       \
+        *reinterpret_cast<float4*>(a_ + a_loff[0]) = ra0;                                        \
+        *reinterpret_cast<float4*>(a_ + a_loff[1]) = ra1;                                        \
+        *reinterpret_cast<float4*>(a_ + a_loff[2]) = ra2;                                        \
+        *reinterpret_cast<float4*>(a_ + a_loff[3]) = ra3;                                        \
+    }
+#define MSR_MMA3(m, n, AH, AL, BH, BL)                                                           \
+    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL, BH, acc[m][n], 0, 0, 0);             \
+    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BL, acc[m][n], 0, 0, 0);             \
+    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BH, acc[m][n], 0, 0, 0);
+#define MSR_COMPUTE(buf, S)                                                                      \
+    {                                                                                            \
+        const float* a_ = As + (buf) * BM * BKP;                                                 \
+        bf16x8 ah[MT], al[MT];                                                                   \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                         \
+            ah[m] = *reinterpret_cast<const bf16x8*>(a_ + a_frag[m]);                            \
+            al[m] = *reinterpret_cast<const bf16x8*>(a_ + a_frag[m] + 16);                       \
+        }                                                                                        \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                         \
+            MSR_MMA3(m, 0, ah[m], al[m], S##00h, S##00l)                                         \
+            MSR_MMA3(m, 1, ah[m], al[m], S##10h, S##10l)                                         \
+        }                                                                                        \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                         \
+            ah[m] = *reinterpret_cast<const bf16x8*>(a_ + a_frag[m] + 8);                        \
+            al[m] = *reinterpret_cast<const bf16x8*>(a_ + a_frag[m] + 8 + 16);                   \
+        }                                                                                        \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                         \
+            MSR_MMA3(m, 0, ah[m], al[m], S##01h, S##01l)                                         \
+            MSR_MMA3(m, 1, ah[m], al[m], S##11h, S##11l)                                         \
+        }                                                                                        \
+    }
+#define MSR_STEP(CUR, NXT)                                                                       \
+    {                                                                                            \
+        MSR_ADVANCE();                                                                           \
+        MSR_LOAD_A();                                                                            \
+        MSR_LOAD_B(NXT);                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        MSR_COMPUTE(cur, CUR);                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        MSR_WRITE_A(cur ^ 1);                                                                    \
+        __syncthreads();                                                                         \
+        cur ^= 1;                                                                                \
+    }
+
+    MSR_LOAD_A();
+    MSR_LOAD_B(P);
+    MSR_WRITE_A(0);
+    __syncthreads();
+    int cur = 0;
+    const int nsteps = t_end - t_begin;
+    int i = 0;
+    for (; i + 2 <= nsteps - 1; i += 2) {
+        MSR_STEP(P, Q);
+        MSR_STEP(Q, P);
+    }
+    if ((nsteps - 1) & 1) {
+        MSR_STEP(P, Q);
+        MSR_COMPUTE(cur, Q);
+    } else {
+        MSR_COMPUTE(cur, P);
+    }
+#undef MSR_LDB
+#undef MSR_LOAD_B
+#undef MSR_LOAD_A
+#undef MSR_ADVANCE
+#undef MSR_WRITE_A
+#undef MSR_MMA3
+#undef MSR_COMPUTE
+#undef MSR_STEP
+
+    conv_epilogue<WM, WN, MT, NT, EPI>(p, g, acc, ks, wm, wn, half, l31, n0, tx0, ty0, b0);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// conv_igemm_bf16x3_halo: split-bf16, 3x3 stride 1, LDS-staged INPUT HALO tile.
+//
+// The generic kernel re-stages the 128-pixel activation tile for each of the 9 taps.  Here the workgroup's
+// 8 x 16 pixel tile is staged once per 32-channel chunk together with its one-pixel halo ((8+2) x (16+2) = 180
+// pixels x 128 bytes) and the nine taps read it at nine constant LDS offsets: activation traffic (global -> LDS
+// and LDS writes) drops ~9x; the weight tile (128 channels x 128 bytes per K-step) is double-buffered as before.
+// K order: chunk outer, tap inner (unrolled).  At the chunk seam: barrier, halo write, barrier.
+// LDS: 180*144 + 2*128*144 = 62.8 KB -> 2 workgroups per CU.
+// ------------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+conv_igemm_bf16x3_halo(const ConvParams p, const TileGeom g) {
+    constexpr int WM = 2, WN = 2, MT = 2, NT = 2;
+    constexpr int NTHR = 256, BM = 128, BN = 128, BKC = 32, BKP = 36;
+    constexpr int TH = 8, TW = 16, HH = TH + 2, HW = TW + 2, HP = HH * HW;   // 180 halo pixels
+    constexpr int H_ITEMS = (HP * 8 + NTHR - 1) / NTHR;                        // 6 16-byte items per thread
+    static_assert(H_ITEMS == 6, "halo staging is written for 6 items per thread");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const Ah = smem;                       // [HP][BKP]
+    float* const Bs = smem + HP * BKP;            // [2][BN][BKP]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = bid % g.tiles_n;
+    int tmi = bid / g.tiles_n;
+    const int tx0 = (tmi % g.tiles_x) << g.tw_l;
+    tmi /= g.tiles_x;
+    const int ty0 = (tmi % g.tiles_y) << g.th_l;
+    const int b0 = tmi / g.tiles_y;               // tb == 1
+    const int n0 = tn * BN;
+
+    // halo staging items (items past the end duplicate the last one: same bytes to the same LDS slot)
+    int h_goff[H_ITEMS], h_loff[H_ITEMS];
+#pragma unroll
+    for (int q = 0; q < H_ITEMS; ++q) {
+        int idx = tid + q * NTHR;
+        idx = idx < HP * 8 ? idx : HP * 8 - 1;
+        const int hp = idx >> 3, seg = idx & 7;
+        const int hy = hp / HW, hx = hp - hy * HW;
+        h_goff[q] = b0 * p.in_pb + (ty0 + hy) * p.in_py + (tx0 + hx) * p.Cin + seg * 4;
+        h_loff[q] = hp * BKP + seg * 4;
+    }
+    int b_goff[4], b_loff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int idx = tid + q * NTHR;
+        const int row = idx >> 3, seg = idx & 7;
+        b_goff[q] = (n0 + row) * p.Cin + seg * 4;
+        b_loff[q] = row * BKP + seg * 4;
+    }
+    int a_frag[MT], b_frag[NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
+        const int row = (wm * MT + m) * 32 + l31;          // pixel (row >> 4, row & 15) of the 8 x 16 tile
+        a_frag[m] = ((row >> 4) * HW + (row & 15)) * BKP + 4 * half;
+    }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int tx = row & twm, ty = (row >> g.tw_l) & thm, tbi = row >> (g.tw_l + g.th_l);
-            const int bb = b0 + tbi;
-            if (tbi >= g.tb || bb >= p.B) continue;
-            const int y = ty0 + ty, x = tx0 + tx;
-            float* orow = p.out + (size_t)p.out_off + (size_t)bb * p.out_pb + y * p.out_py + x * p.out_px;
-            if constexpr (EPI == EPI_SPADE) {
-                const float* xrow = p.aux + (size_t)bb * p.aux_pb + (y >> p.aux_shift) * p.aux_py +
-                                    (x >> p.aux_shift) * p.aux_px;
+    for (int n = 0; n < NT; ++n) b_frag[n] = ((wn * NT + n) * 32 + l31) * BKP + 4 * half;
+
+    f32x16 acc[MT][NT];
 #pragma unroll
-                for (int j = 0; j < NCH; ++j) {
-                    const float gam = acc[m][2 * j][r] + cb0[j];
-                    const float bet = acc[m][2 * j + 1][r] + cb1[j];
-                    const float normalized = (xrow[ccol[j]] - cmean[j]) / cstd[j];
-                    float v = gam * normalized + bet;
-                    v = v >= 0.f ? v : v * p.slope;
-                    orow[ccol[j]] = p.out_split ? msr_split_bf16(v) : v;
-                }
-            } else {
-                const float* rrow = nullptr;
-                if constexpr (EPI == EPI_RES)
-                    rrow = p.aux + (size_t)bb * p.aux_pb + (y >> p.aux_shift) * p.aux_py +
-                           (x >> p.aux_shift) * p.aux_px;
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    float v = acc[m][n][r] + cb0[n];
-                    if constexpr (EPI == EPI_RES) v += rrow[ccol[n]];
-                    orow[ccol[n]] = v;
-                }
-            }
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const int chunks = p.Cin / BKC;
+    const size_t w_tap_stride = (size_t)p.N * p.Cin;
+    const float* h_src = p.in;                    // + cc*BKC
+    const float* b_src = p.wt;                    // + tap*N*Cin + cc*BKC
+
+    float4 rh0, rh1, rh2, rh3, rh4, rh5, rb0, rb1, rb2, rb3;
+#define MSR_LOAD_H()                                                                             \
+    {                                                                                            \
+        rh0 = *reinterpret_cast<const float4*>(h_src + h_goff[0]);                               \
+        rh1 = *reinterpret_cast<const float4*>(h_src + h_goff[1]);                               \
+        rh2 = *reinterpret_cast<const float4*>(h_src + h_goff[2]);                               \
+        rh3 = *reinterpret_cast<const float4*>(h_src + h_goff[3]);                               \
+        rh4 = *reinterpret_cast<const float4*>(h_src + h_goff[4]);                               \
+        rh5 = *reinterpret_cast<const float4*>(h_src + h_goff[5]);                               \
+    }
+#define MSR_WRITE_H()                                                                            \
+    {                                                                                            \
+        *reinterpret_cast<float4*>(Ah + h_loff[0]) = rh0;                                        \
+        *reinterpret_cast<float4*>(Ah + h_loff[1]) = rh1;                                        \
+        *reinterpret_cast<float4*>(Ah + h_loff[2]) = rh2;                                        \
+        *reinterpret_cast<float4*>(Ah + h_loff[3]) = rh3;                                        \
+        *reinterpret_cast<float4*>(Ah + h_loff[4]) = rh4;                                        \
+        *reinterpret_cast<float4*>(Ah + h_loff[5]) = rh5;                                        \
+    }
+#define MSR_LOAD_B(ptr)                                                                          \
+    {                                                                                            \
+        rb0 = *reinterpret_cast<const float4*>((ptr) + b_goff[0]);                               \
+        rb1 = *reinterpret_cast<const float4*>((ptr) + b_goff[1]);                               \
+        rb2 = *reinterpret_cast<const float4*>((ptr) + b_goff[2]);                               \
+        rb3 = *reinterpret_cast<const float4*>((ptr) + b_goff[3]);                               \
+    }
+#define MSR_WRITE_B(buf)                                                                         \
+    {                                                                                            \
+        float* b_ = Bs + (buf) * BN * BKP;                                                       \
+        *reinterpret_cast<float4*>(b_ + b_loff[0]) = rb0;                                        \
+        *reinterpret_cast<float4*>(b_ + b_loff[1]) = rb1;                                        \
+        *reinterpret_cast<float4*>(b_ + b_loff[2]) = rb2;                                        \
+        *reinterpret_cast<float4*>(b_ + b_loff[3]) = rb3;                                        \
+    }
+#define MSR_COMPUTE(buf, TAPOFF)                                                                 \
+    {                                                                                            \
+        const float* a_ = Ah + (TAPOFF);                                                         \
+        const float* b_ = Bs + (buf) * BN * BKP;                                                 \
+        _Pragma("unroll") for (int kg = 0; kg < 2; ++kg) {                                       \
+            bf16x8 ah[MT], al[MT], bh[NT], bl[NT];                                               \
+            _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                     \
+                ah[m] = *reinterpret_cast<const bf16x8*>(a_ + a_frag[m] + kg * 8);               \
+                al[m] = *reinterpret_cast<const bf16x8*>(a_ + a_frag[m] + kg * 8 + 16);          \
+            }                                                                                    \
+            _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                     \
+                bh[n] = *reinterpret_cast<const bf16x8*>(b_ + b_frag[n] + kg * 8);               \
+                bl[n] = *reinterpret_cast<const bf16x8*>(b_ + b_frag[n] + kg * 8 + 16);          \
+            }                                                                                    \
+            _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                     \
+                _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                 \
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0); \
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0); \
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0); \
+                }                                                                                \
+            }                                                                                    \
+        }                                                                                        \
+    }
+// taps 0..7 of a chunk: prefetch the next tap's weights, compute, write them to the other buffer
+#define MSR_TAP(T)                                                                               \
+    {                                                                                            \
+        MSR_LOAD_B(b_src + (size_t)((T) + 1) * w_tap_stride);                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        MSR_COMPUTE(cur, (((T) / 3) * HW + ((T) % 3)) * BKP);                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        MSR_WRITE_B(cur ^ 1);                                                                    \
+        __syncthreads();                                                                         \
+        cur ^= 1;                                                                                \
+    }
+
+    MSR_LOAD_H();
+    MSR_LOAD_B(b_src);
+    MSR_WRITE_H();
+    MSR_WRITE_B(0);
+    __syncthreads();
+    int cur = 0;
+    for (int cc = 0; cc < chunks; ++cc) {
+        MSR_TAP(0) MSR_TAP(1) MSR_TAP(2) MSR_TAP(3) MSR_TAP(4) MSR_TAP(5) MSR_TAP(6) MSR_TAP(7)
+        // tap 8: the seam.  Prefetch the next chunk's halo and its tap-0 weights (if any).
+        const bool more = cc + 1 < chunks;
+        if (more) {
+            h_src += BKC;
+            b_src += BKC;
+            MSR_LOAD_H();
+            MSR_LOAD_B(b_src);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        MSR_COMPUTE(cur, (2 * HW + 2) * BKP);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            __syncthreads();            // every wave is done with the old halo
+            MSR_WRITE_H();
+            MSR_WRITE_B(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
         }
     }
+#undef MSR_LOAD_H
+#undef MSR_WRITE_H
+#undef MSR_LOAD_B
+#undef MSR_WRITE_B
+#undef MSR_COMPUTE
+#undef MSR_TAP
+
+    conv_epilogue<WM, WN, MT, NT, EPI>(p, g, acc, 0, wm, wn, half, l31, n0, tx0, ty0, b0);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -416,14 +799,11 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(const ConvParams p
                 v.w = v.w * ((xv.w - mu.w) / sd.w) + (bsum.w + b1v.w);
                 v.x = v.x >= 0.f ? v.x : v.x * p.slope; v.y = v.y >= 0.f ? v.y : v.y * p.slope;
                 v.z = v.z >= 0.f ? v.z : v.z * p.slope; v.w = v.w >= 0.f ? v.w : v.w * p.slope;
-                if (p.out_split) {
-                    v.x = msr_split_bf16(v.x); v.y = msr_split_bf16(v.y);
-                    v.z = msr_split_bf16(v.z); v.w = msr_split_bf16(v.w);
-                }
             }
         }
-        float* o = p.out + (size_t)p.out_off + (size_t)b * p.out_pb + (size_t)y * p.out_py + (size_t)x * p.out_px + c;
-        *reinterpret_cast<float4*>(o) = v;
+        float* opix = p.out + (size_t)p.out_off + (size_t)b * p.out_pb + (size_t)y * p.out_py + (size_t)x * p.out_px;
+        if (EPI == EPI_SPADE && p.out_split) msr_store_split4(opix, c, v.x, v.y, v.z, v.w);
+        else *reinterpret_cast<float4*>(opix + c) = v;
     }
 }
 
@@ -452,13 +832,48 @@ static hipError_t set_attr_all() {
     return set_attr<WM, WN, MT, NT, BKC, EPI_PARTIAL, PREC>();
 }
 
+template <int WM, int WN, int MT, int NT>
+struct TileCfgB {   // split-bf16 kernel: only the activation tile lives in LDS
+    static constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NTHR = WM * WN * 64;
+    static constexpr size_t LDS = (size_t)(2 * BM) * 36 * sizeof(float);
+};
+
+template <int WM, int WN, int MT, int NT>
+static hipError_t set_attr_bf16x3() {
+    hipError_t e;
+    const int lds = (int)TileCfgB<WM, WN, MT, NT>::LDS;
+#define MSR_SET(EPI)                                                                                          \
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3<WM, WN, MT, NT, EPI>),       \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess)              \
+        return e;
+    MSR_SET(EPI_BIAS) MSR_SET(EPI_RES) MSR_SET(EPI_SPADE) MSR_SET(EPI_PARTIAL)
+#undef MSR_SET
+    return hipSuccess;
+}
+
+static constexpr size_t HALO_LDS = (size_t)(180 + 2 * 128) * 36 * sizeof(float);
+
+static hipError_t set_attr_halo() {
+    hipError_t e;
+#define MSR_SET(EPI)                                                                                          \
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_halo<EPI>),                  \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)HALO_LDS)) != hipSuccess)    \
+        return e;
+    MSR_SET(EPI_BIAS) MSR_SET(EPI_RES) MSR_SET(EPI_SPADE)
+#undef MSR_SET
+    return hipSuccess;
+}
+
 hipError_t conv_igemm_init() {
     hipError_t e;
+    if ((e = set_attr_halo()) != hipSuccess) return e;
     if ((e = set_attr_all<2, 2, 2, 2, 32, PREC_F32>()) != hipSuccess) return e;
     if ((e = set_attr_all<2, 1, 1, 2, 32, PREC_F32>()) != hipSuccess) return e;
     if ((e = set_attr_all<2, 2, 2, 2, 16, PREC_F32>()) != hipSuccess) return e;
     if ((e = set_attr_all<2, 2, 2, 2, 32, PREC_BF16X3>()) != hipSuccess) return e;
-    return set_attr_all<2, 1, 1, 2, 32, PREC_BF16X3>();
+    if ((e = set_attr_all<2, 1, 1, 2, 32, PREC_BF16X3>()) != hipSuccess) return e;
+    if ((e = set_attr_bf16x3<2, 2, 2, 2>()) != hipSuccess) return e;
+    return set_attr_bf16x3<2, 1, 1, 2>();
 }
 
 static int ilog2_floor(int v) {
@@ -542,8 +957,53 @@ static hipError_t launch_cfg(const ConvParams& p, int epi, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <int WM, int WN, int MT, int NT>
+static hipError_t launch_bf16x3(const ConvParams& p, int epi, hipStream_t s) {
+    using C = TileCfgB<WM, WN, MT, NT>;
+    TileGeom g;
+    if (!make_geom(p, C::BM, C::BN, 32, g)) return hipErrorInvalidValue;
+    const int grid = g.tiles_mn * (p.ksplit > 1 ? p.ksplit : 1);
+    if (p.ksplit > 1) {
+        if (!p.partial || epi == EPI_PARTIAL) return hipErrorInvalidValue;
+        conv_igemm_bf16x3<WM, WN, MT, NT, EPI_PARTIAL><<<grid, C::NTHR, C::LDS, s>>>(p, g);
+        const int Cout = epi == EPI_SPADE ? p.N / 2 : p.N;
+        long eb = ((long)p.B * p.Hout * p.Wout * (Cout / 4) + 255) / 256;
+        if (eb > 4096) eb = 4096;
+        if (epi == EPI_BIAS) splitk_epilogue_kernel<EPI_BIAS><<<(int)eb, 256, 0, s>>>(p);
+        else if (epi == EPI_RES) splitk_epilogue_kernel<EPI_RES><<<(int)eb, 256, 0, s>>>(p);
+        else splitk_epilogue_kernel<EPI_SPADE><<<(int)eb, 256, 0, s>>>(p);
+        return hipGetLastError();
+    }
+    switch (epi) {
+        case EPI_BIAS: conv_igemm_bf16x3<WM, WN, MT, NT, EPI_BIAS><<<grid, C::NTHR, C::LDS, s>>>(p, g); break;
+        case EPI_RES: conv_igemm_bf16x3<WM, WN, MT, NT, EPI_RES><<<grid, C::NTHR, C::LDS, s>>>(p, g); break;
+        case EPI_SPADE: conv_igemm_bf16x3<WM, WN, MT, NT, EPI_SPADE><<<grid, C::NTHR, C::LDS, s>>>(p, g); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+static hipError_t launch_halo(const ConvParams& p, int epi, hipStream_t s) {
+    TileGeom g;
+    if (!make_geom(p, 128, 128, 32, g)) return hipErrorInvalidValue;
+    if (g.tb != 1 || g.th_l != 3 || g.tw_l != 4 || p.stride != 1 || p.KH != 3 || p.KW != 3 || p.ksplit > 1)
+        return hipErrorInvalidValue;
+    switch (epi) {
+        case EPI_BIAS: conv_igemm_bf16x3_halo<EPI_BIAS><<<g.tiles_mn, 256, HALO_LDS, s>>>(p, g); break;
+        case EPI_RES: conv_igemm_bf16x3_halo<EPI_RES><<<g.tiles_mn, 256, HALO_LDS, s>>>(p, g); break;
+        case EPI_SPADE: conv_igemm_bf16x3_halo<EPI_SPADE><<<g.tiles_mn, 256, HALO_LDS, s>>>(p, g); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_conv_igemm(const ConvParams& p, int epilogue, int tile, hipStream_t s) {
     if (p.prec == PREC_BF16X3) {
+        if (tile == TILE_128x128_HALO) return launch_halo(p, epilogue, s);
+        if (p.wt_frag) {
+            if (tile == TILE_64x64) return launch_bf16x3<2, 1, 1, 2>(p, epilogue, s);
+            return launch_bf16x3<2, 2, 2, 2>(p, epilogue, s);
+        }
         if (tile == TILE_64x64) return launch_cfg<2, 1, 1, 2, 32, PREC_BF16X3>(p, epilogue, s);
         return launch_cfg<2, 2, 2, 2, 32, PREC_BF16X3>(p, epilogue, s);
     }

@@ -41,13 +41,16 @@ struct ConvParams {
     int ksplit;                   // > 1: the K loop is cut into ksplit ranges, one workgroup each (low-res layers)
     float* partial;               // [ksplit][B*Hout*Wout][N] workspace for split-K
     int prec;                     // PREC_F32: operands are fp32; PREC_BF16X3: operands are split-bf16 words
-    int out_split;                // EPI_SPADE only: write split-bf16 words (the consumer conv runs PREC_BF16X3)
+    int out_split;                // EPI_SPADE only: write the split-bf16 image (the consumer conv runs PREC_BF16X3)
+    int wt_frag;                  // PREC_BF16X3: weights are in MFMA-fragment order (conv_igemm_bf16x3, B in VGPRs)
+                                  // instead of the split-bf16 image of [tap][N][Cin] (LDS-staged B)
 };
 
-// Split-bf16 operand format ("bf16x3"): a 32-bit word holds hi = bf16_rn(v) in its low half and
-// lo = bf16_rn(v - hi) in its high half, so tensors keep their fp32 addressing.  The conv computes
-// a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: per-product error
-// <= ~3*2^-18 instead of fp32's 2^-24, at 16/3 of the fp32-MFMA rate.
+// Split-bf16 operand format ("bf16x3"): tensors keep their fp32 size and addressing, but every aligned group of
+// 32 channels (128 bytes) holds [32 x hi bf16 | 32 x lo bf16] with hi = bf16_rn(v), lo = bf16_rn(v - hi).
+// That is exactly the LDS row image the kernel wants (8 consecutive k of one half per ds_read_b128), so staging
+// is a plain 16-byte copy.  The conv computes a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 with
+// fp32 accumulation: per-product error <= ~3*2^-18 instead of fp32's 2^-24, at 16/3 of the fp32-MFMA rate.
 enum ConvPrecision : int { PREC_F32 = 0, PREC_BF16X3 = 1 };
 
 __host__ __device__ inline unsigned msr_bf16_rn(float v) {   // round-to-nearest-even, finite inputs
@@ -55,16 +58,24 @@ __host__ __device__ inline unsigned msr_bf16_rn(float v) {   // round-to-nearest
     c.f = v;
     return (c.u + 0x7FFFu + ((c.u >> 16) & 1u)) >> 16;
 }
-__host__ __device__ inline float msr_split_bf16(float v) {
+__host__ __device__ inline void msr_split_bf16(float v, unsigned& hi, unsigned& lo) {
     union { float f; unsigned u; } c;
-    const unsigned hi = msr_bf16_rn(v);
+    hi = msr_bf16_rn(v);
     c.u = hi << 16;
-    const unsigned lo = msr_bf16_rn(v - c.f);
-    c.u = hi | (lo << 16);
-    return c.f;
+    lo = msr_bf16_rn(v - c.f);
+}
+// 4 consecutive channels c..c+3 (c % 4 == 0) of one pixel -> two 8-byte stores into the pixel's chunk image.
+// `pixel` points at channel 0 of the pixel (float units).
+__host__ __device__ inline void msr_store_split4(float* pixel, int c, float v0, float v1, float v2, float v3) {
+    unsigned h0, l0, h1, l1, h2, l2, h3, l3;
+    msr_split_bf16(v0, h0, l0); msr_split_bf16(v1, h1, l1); msr_split_bf16(v2, h2, l2); msr_split_bf16(v3, h3, l3);
+    unsigned* chunk = reinterpret_cast<unsigned*>(pixel) + (c & ~31);
+    const int w = (c & 31) >> 1;
+    chunk[w] = h0 | (h1 << 16); chunk[w + 1] = h2 | (h3 << 16);
+    chunk[16 + w] = l0 | (l1 << 16); chunk[16 + w + 1] = l2 | (l3 << 16);
 }
 
-enum ConvTile : int { TILE_128x128 = 0, TILE_64x64 = 1, TILE_128x128_K16 = 2 };
+enum ConvTile : int { TILE_128x128 = 0, TILE_64x64 = 1, TILE_128x128_K16 = 2, TILE_128x128_HALO = 3 };
 
 hipError_t conv_igemm_init();   // sets dynamic-LDS attributes once
 hipError_t launch_conv_igemm(const ConvParams& p, int epilogue, int tile, hipStream_t s);

@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256) conv_smallcin_kernel(const SmallCinParams
                                 : make_float2(0.f, 0.f);
             }
         }
-        float* o = p.out + (size_t)p.out_off + (size_t)b * p.out_pb + (size_t)y * p.out_py + (size_t)x0 * p.out_px + q * 4;
+        float* o = p.out + (size_t)p.out_off + (size_t)b * p.out_pb + (size_t)y * p.out_py + (size_t)x0 * p.out_px;
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
             float4 acc = bias;
@@ -76,11 +76,8 @@ __global__ void __launch_bounds__(256) conv_smallcin_kernel(const SmallCinParams
                 acc.x = acc.x >= 0.f ? acc.x : acc.x * p.slope; acc.y = acc.y >= 0.f ? acc.y : acc.y * p.slope;
                 acc.z = acc.z >= 0.f ? acc.z : acc.z * p.slope; acc.w = acc.w >= 0.f ? acc.w : acc.w * p.slope;
             }
-            if (p.out_split) {
-                acc.x = msr_split_bf16(acc.x); acc.y = msr_split_bf16(acc.y);
-                acc.z = msr_split_bf16(acc.z); acc.w = msr_split_bf16(acc.w);
-            }
-            *reinterpret_cast<float4*>(o + (size_t)i * p.out_px) = acc;
+            if (p.out_split) msr_store_split4(o + (size_t)i * p.out_px, q * 4, acc.x, acc.y, acc.z, acc.w);
+            else *reinterpret_cast<float4*>(o + (size_t)i * p.out_px + q * 4) = acc;
         }
     }
 }
@@ -104,11 +101,18 @@ hipError_t launch_conv_smallcin(const SmallCinParams& p, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
+// fp32 -> split-bf16 chunk image; the innermost dimension must be a multiple of 32 (n % 32 == 0)
 __global__ void __launch_bounds__(256) split_bf16_kernel(const float* __restrict__ in, float* __restrict__ out, long n) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = msr_split_bf16(in[i]);
+    const long quads = n / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < quads; i += (long)gridDim.x * 256) {
+        const float4 v = *reinterpret_cast<const float4*>(in + i * 4);
+        const long e = i * 4;
+        msr_store_split4(out + (e & ~31L), (int)(e & 31), v.x, v.y, v.z, v.w);
+    }
 }
 hipError_t launch_split_bf16(const float* in, float* out, long n, hipStream_t s) {
-    long blocks = (n + 255) / 256;
+    if (n % 32) return hipErrorInvalidValue;
+    long blocks = (n / 4 + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     if (n > 0) split_bf16_kernel<<<(int)blocks, 256, 0, s>>>(in, out, n);
     return hipGetLastError();
@@ -242,11 +246,9 @@ __global__ void __launch_bounds__(256) norm_act_kernel(const NormActParams p) {
         r.w = (v.w - m.w) / sd.w * ga.w + be.w;
         r.x = r.x >= 0.f ? r.x : r.x * p.slope; r.y = r.y >= 0.f ? r.y : r.y * p.slope;
         r.z = r.z >= 0.f ? r.z : r.z * p.slope; r.w = r.w >= 0.f ? r.w : r.w * p.slope;
-        if (p.out_split) {
-            r.x = msr_split_bf16(r.x); r.y = msr_split_bf16(r.y); r.z = msr_split_bf16(r.z); r.w = msr_split_bf16(r.w);
-        }
-        float* o = p.out + (size_t)p.out_off + (size_t)b * p.out_pb + (size_t)y * p.out_py + (size_t)x * p.out_px + q * 4;
-        *reinterpret_cast<float4*>(o) = r;
+        float* o = p.out + (size_t)p.out_off + (size_t)b * p.out_pb + (size_t)y * p.out_py + (size_t)x * p.out_px;
+        if (p.out_split) msr_store_split4(o, q * 4, r.x, r.y, r.z, r.w);
+        else *reinterpret_cast<float4*>(o + q * 4) = r;
     }
 }
 

@@ -9,6 +9,7 @@ import torch
 from . import _lib
 
 EPI_BIAS, EPI_RES, EPI_SPADE = 0, 1, 2
+TILE_128, TILE_64, TILE_128_K16, TILE_HALO, TILE_FRAG = 0, 1, 2, 3, 0x40
 
 
 class OpContext:
@@ -75,13 +76,27 @@ def split_bf16(ctx: OpContext, x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def weights_bf16x3(w_kl: torch.Tensor) -> torch.Tensor:
+    """Kernel-layout weights [taps][N][Cin] (fp32) -> the MFMA-fragment order conv_igemm_bf16x3 reads:
+    [tap][chunk][n-tile][kg][hi|lo][lane = 32*h + j][8 bf16], returned as float32 storage of the same size."""
+    taps, N, Cin = w_kl.shape
+    hi = w_kl.to(torch.bfloat16)
+    lo = (w_kl - hi.float()).to(torch.bfloat16)
+    hl = torch.stack([hi, lo], 0)                                        # [2][tap][N][Cin]
+    hl = hl.reshape(2, taps, N // 32, 32, Cin // 32, 2, 2, 8)            # [hl][tap][nt][j][cc][kg][h][e]
+    hl = hl.permute(1, 4, 2, 5, 0, 6, 3, 7).contiguous()                 # [tap][cc][nt][kg][hl][h][j][e]
+    return hl.view(torch.int16).reshape(-1).view(torch.float32).reshape(taps, N, Cin)
+
+
 def conv3x3(ctx: OpContext, x_padded: torch.Tensor, w_kl: torch.Tensor, bias: torch.Tensor, rout: int, stride: int = 1,
             epilogue: int = EPI_BIAS, aux: Optional[torch.Tensor] = None, aux_shift: int = 0,
             mean: Optional[torch.Tensor] = None, std: Optional[torch.Tensor] = None, out_padded: bool = False,
             tile: int = -1, out: Optional[torch.Tensor] = None, precision: str = "fp32",
             out_split: bool = False) -> torch.Tensor:
     """One conv_igemm launch on torch's current stream.  x_padded [B, rout*stride+2, ., Cin].
-    precision="bf16x3": x_padded and w_kl must already hold split-bf16 words (``split_bf16``)."""
+    precision="bf16x3": x_padded must hold the split-bf16 chunk image (``split_bf16``); w_kl either the
+    split-bf16 image of the kernel layout (``split_bf16(kernel_layout(w))``; tiles 0, 1 and 3 = halo) or, with
+    tile | TILE_FRAG, the fragment-order weights (``weights_bf16x3``; tiles 0 and 1, weights kept in VGPRs)."""
     B, Cin = x_padded.shape[0], x_padded.shape[3]
     N = w_kl.shape[1]
     Cout = N // 2 if epilogue == EPI_SPADE else N

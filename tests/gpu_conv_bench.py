@@ -26,7 +26,7 @@ for name, r, cin, N, epi in shapes:
     std = torch.ones(C, device="cuda") if epi == 2 else None
     out = torch.zeros((B, r + 2, r + 2, C), device="cuda") if epi == 2 else torch.empty((B, r, r, C), device="cuda")
     line = f"{name:10s} r={r:4d} Cin={cin:5d} N={N:5d}"
-    for tile, prec in ((0, "fp32"), (2, "fp32"), (1, "fp32"), (0, "bf16x3"), (1, "bf16x3")):
+    for tile, prec in ((0, "fp32"), (0, "bf16x3"), (0x40, "bf16x3"), (3, "bf16x3"), (1, "bf16x3"), (0x41, "bf16x3")):
         try:
             kw = dict(epilogue=epi, aux=aux, mean=mean, std=std, out_padded=(epi == 2), tile=tile, out=out, precision=prec)
             for _ in range(2):
@@ -38,7 +38,7 @@ for name, r, cin, N, epi in shapes:
                 ops.conv3x3(ctx, x, w, bias, r, **kw)
             b.record(); torch.cuda.synchronize()
             ms = a.elapsed_time(b) / n
-            line += f" | t{tile}{prec[:2]}: {ms:6.3f} ms {2.0 * B * r * r * cin * N * 9 / ms / 1e9:6.1f}"
+            line += f" | {tile:02x}{prec[:2]}: {ms:6.3f} {2.0 * B * r * r * cin * N * 9 / ms / 1e9:6.1f}"
         except ValueError as e:
-            line += f" | t{tile}{prec[:2]}: n/a"
+            line += f" | {tile:02x}{prec[:2]}: n/a"
     print(line, flush=True)

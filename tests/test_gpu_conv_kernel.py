@@ -93,38 +93,49 @@ def test_untileable_shape_is_rejected(ctx):
         ops.conv3x3(ctx, x, w, torch.zeros(64, device="cuda"), 12)
 
 
+@pytest.mark.parametrize("frag", [0, 0x40])
 @pytest.mark.parametrize("B,r,cin,cout,stride,tile", [
     (2, 16, 64, 128, 1, 0), (2, 16, 64, 128, 1, 1), (3, 8, 32, 64, 1, 1), (2, 16, 64, 128, 2, 1),
-    (2, 8, 128, 128, 1, 1 + 256 * 4), (16, 1, 64, 64, 1, 1)])
-def test_conv_bf16x3(ctx, B, r, cin, cout, stride, tile):
-    """3-term split-bf16 products, fp32 accumulation: error bound ~3*2^-18 per product -> rel L-inf <= 5e-5."""
+    (2, 8, 128, 128, 1, 1 + 256 * 4), (16, 1, 64, 64, 1, 1), (2, 16, 64, 128, 1, 3), (1, 32, 96, 256, 1, 3)])
+def test_conv_bf16x3(ctx, B, r, cin, cout, stride, tile, frag):
+    """3-term split-bf16 products, fp32 accumulation: error bound ~3*2^-18 per product -> rel L-inf <= 5e-5.
+    Three kernels: LDS-staged weights (tiles 0/1), weights in VGPRs (| 0x40), LDS-staged input halo (tile 3)."""
     from moonsuperresolution_amd import ops
+    if frag and (tile & 0x3F) == 3:
+        pytest.skip("the halo kernel stages its weights through LDS")
     g = torch.Generator(device="cpu").manual_seed(B * 1000 + r + 1)
     rin = r * stride
     x = torch.randn((B, rin, rin, cin), generator=g).cuda()
     w = (torch.randn((3, 3, cin, cout), generator=g) / np.sqrt(9 * cin)).cuda()
     b = torch.randn(cout, generator=g).cuda()
     xs = ops.split_bf16(ctx, ops.pad_nhwc(x))
-    ws = ops.split_bf16(ctx, ops.kernel_layout(w))
-    y = ops.conv3x3(ctx, xs, ws, b, r, stride=stride, tile=tile, precision="bf16x3")
+    ws = ops.weights_bf16x3(ops.kernel_layout(w)) if frag else ops.split_bf16(ctx, ops.kernel_layout(w))
+    y = ops.conv3x3(ctx, xs, ws, b, r, stride=stride, tile=tile | frag, precision="bf16x3")
     err = rel_linf(y.cpu().numpy(), ref_conv(x, w, b, stride).numpy())
     assert err <= 5e-5, err
+
+
+def unsplit(t):
+    """split-bf16 chunk image -> (hi + lo) float32 values, same shape (innermost dim % 32 == 0)."""
+    u = t.contiguous().view(torch.int16).reshape(-1, 2, 32).to(torch.int32) & 0xFFFF
+    hi = (u[:, 0] << 16).view(torch.float32)
+    lo = (u[:, 1] << 16).view(torch.float32)
+    return hi.reshape(t.shape), lo.reshape(t.shape)
 
 
 def test_split_bf16_words(ctx):
     from moonsuperresolution_amd import ops
     x = torch.randn(4096, device="cuda") * torch.logspace(-6, 6, 4096, device="cuda")
-    w = ops.split_bf16(ctx, x).view(torch.int32)
-    hi = ((w & 0xFFFF) << 16).view(torch.float32)
-    lo = (w & -65536).view(torch.float32)
+    hi, lo = unsplit(ops.split_bf16(ctx, x))
     assert torch.equal(hi, x.to(torch.bfloat16).float())                       # hi = round-to-nearest-even bf16
     assert torch.equal(lo, (x - hi).to(torch.bfloat16).float())
     assert float(((hi + lo) - x).abs().max() / x.abs().max()) < 2 ** -16
-    z = ops.split_bf16(ctx, torch.zeros(8, device="cuda"))
+    z = ops.split_bf16(ctx, torch.zeros(64, device="cuda"))
     assert float(z.abs().max()) == 0.0                                         # the zero border stays zero
 
 
-def test_conv_spade_epilogue_bf16x3_split_output(ctx):
+@pytest.mark.parametrize("tile", [0, 3])
+def test_conv_spade_epilogue_bf16x3_split_output(ctx, tile):
     from moonsuperresolution_amd import ops
     g = torch.Generator(device="cpu").manual_seed(13)
     B, r, C = 2, 16, 64
@@ -137,9 +148,9 @@ def test_conv_spade_epilogue_bf16x3_split_output(ctx):
     std = torch.sqrt(x.var((0, 1, 2), unbiased=False) + 1e-5).contiguous()
     w, bias = ops.spade_layout(wg, wb, bg, bb)
     y = ops.conv3x3(ctx, ops.split_bf16(ctx, ops.pad_nhwc(h)), ops.split_bf16(ctx, w), bias, r, epilogue=ops.EPI_SPADE,
-                    aux=x, mean=mean, std=std, out_padded=True, tile=0, precision="bf16x3", out_split=True)
-    wds = y.view(torch.int32)
-    val = ((wds & 0xFFFF) << 16).view(torch.float32) + (wds & -65536).view(torch.float32)    # hi + lo
+                    aux=x, mean=mean, std=std, out_padded=True, tile=tile, precision="bf16x3", out_split=True)
+    hi, lo = unsplit(y)
+    val = hi + lo
     v = ref_conv(h, wg, bg, 1) * ((x.double().cpu() - mean.double().cpu()) / std.double().cpu()) + ref_conv(h, wb, bb, 1)
     v = torch.where(v >= 0, v, 0.2 * v)
     assert rel_linf(val.cpu()[:, 1:-1, 1:-1].numpy(), v.numpy()) <= 5e-5
