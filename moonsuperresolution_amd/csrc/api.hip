@@ -265,17 +265,17 @@ int upload_conv_weight(msr_handle* h, const std::string& key, const float* host,
 }
 
 struct ConvVariant { int tile; int wt_frag; };
-ConvVariant pick_conv_variant(int B, int rout, int N, int stride, int epi, int prec);
+ConvVariant pick_conv_variant(int B, int rout, int N, int stride, int epi, int prec, int cin);
 
 // Output resolution of the conv a weight belongs to ("enc.ds3.kernel" -> S>>3, "gen.rb4...." -> sw<<3).
-bool weight_uses_frag(msr_handle* h, const std::string& name, int N, int epi) {
+bool weight_uses_frag(msr_handle* h, const std::string& name, int N, int epi, int cin) {
     if (h->prec != PREC_BF16X3) return false;
     int rout = 0, stride = 1;
     int i = 0;
     if (std::sscanf(name.c_str(), "enc.ds%d.", &i) == 1) { rout = h->S >> i; stride = 2; }
     else if (std::sscanf(name.c_str(), "gen.rb%d.", &i) == 1) rout = (h->S / 64) << (i - 1);
     else return false;
-    return pick_conv_variant(h->B, rout, N, stride, epi, h->prec).wt_frag != 0;
+    return pick_conv_variant(h->B, rout, N, stride, epi, h->prec, cin).wt_frag != 0;
 }
 
 }  // namespace
@@ -447,7 +447,7 @@ int msr_load_weight(msr_handle* h, const char* name_c, const float* host, const 
             img.resize((size_t)9 * 2 * C * cin);
             hwio_to_tap_oc_ic(host, img.data(), 9, cin, C, 2 * C, rowmap.data());
             rc = upload_conv_weight(h, base + ".gb.kernel", img.data(), img.size(), 9, 2 * C, cin,
-                                    weight_uses_frag(h, name, 2 * C, EPI_SPADE));
+                                    weight_uses_frag(h, name, 2 * C, EPI_SPADE, cin));
         }
     } else if (ends_with(name, ".conv_gamma.bias") || ends_with(name, ".conv_beta.bias")) {
         const bool is_beta = ends_with(name, ".conv_beta.bias");
@@ -462,7 +462,7 @@ int msr_load_weight(msr_handle* h, const char* name_c, const float* host, const 
         const int taps = (int)(s[0] * s[1]), cin = (int)s[2], cout = (int)s[3];
         std::vector<float> t(count);
         hwio_to_tap_oc_ic(host, t.data(), taps, cin, cout, cout, nullptr);
-        rc = upload_conv_weight(h, name, t.data(), count, taps, cout, cin, weight_uses_frag(h, name, cout, EPI_BIAS));
+        rc = upload_conv_weight(h, name, t.data(), count, taps, cout, cin, weight_uses_frag(h, name, cout, EPI_BIAS, cin));
     } else {
         rc = upload(h, name, host, count);
     }
@@ -493,13 +493,13 @@ int alloc_padded(msr_handle* h, const std::string& key, int r, int C, Padded* ou
 
 // Kernel variant of one conv layer.  Under bf16x3 it also fixes the weight layout, so msr_load_weight and the
 // planner must agree: both call this.
-ConvVariant pick_conv_variant(int B, int rout, int N, int stride, int epi, int prec) {
+ConvVariant pick_conv_variant(int B, int rout, int N, int stride, int epi, int prec, int cin) {
     ConvVariant v;
     v.tile = conv_pick_tile(B * rout * rout, N, epi, prec);
     v.wt_frag = 0;
     if (prec == PREC_BF16X3) {
         if (v.tile == TILE_64x64) v.wt_frag = 1;                          // B in VGPRs: +18 % on the small tile
-        else if (stride == 1 && rout >= 16) v.tile = TILE_128x128_HALO;   // LDS-staged input halo
+        else if (stride == 1 && rout >= 16 && cin % 64 == 0) v.tile = TILE_128x128_HALO;   // LDS-staged input halo
     }
     return v;
 }
@@ -516,7 +516,7 @@ Op conv_op(const Padded& in, const float* wt, const float* bias, int B, int rout
     c.slope = 0.2f;
     c.prec = prec;
     c.out_split = (epi == EPI_SPADE && prec == PREC_BF16X3) ? 1 : 0;   // a SPADE output always feeds a conv
-    const ConvVariant cv = pick_conv_variant(B, rout, N, stride, epi, prec);
+    const ConvVariant cv = pick_conv_variant(B, rout, N, stride, epi, prec, in.C);
     op.tile = cv.tile;
     c.wt_frag = cv.wt_frag;
     c.ksplit = op.tile == TILE_128x128_HALO ? 1 : conv_pick_ksplit(B * rout * rout, N, 9 * (in.C / 32), op.tile);

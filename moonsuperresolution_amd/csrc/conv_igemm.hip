@@ -639,20 +639,34 @@ conv_igemm_bf16x3_halo(const ConvParams p, const TileGeom g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    const int chunks = p.Cin / BKC;
-    const size_t w_tap_stride = (size_t)p.N * p.Cin;
-    const float* h_src = p.in;                    // + cc*BKC
-    const float* b_src = p.wt;                    // + tap*N*Cin + cc*BKC
+    const int chunks = p.Cin / BKC;               // even (Cin % 64 == 0): the loop body is a PAIR of chunks
+    // Buffer loads: a wave-uniform descriptor + a constant per-lane byte offset (VGPR) + a scalar byte offset that
+    // carries the K-step; no 64-bit per-lane address arithmetic in the unrolled loop.
+    const unsigned w_tap_bytes = (unsigned)((size_t)p.N * p.Cin * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.in), 0, (int)((size_t)p.B * p.in_pb * sizeof(float)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.wt), 0, (int)(9u * w_tap_bytes), 0x00020000);
+    unsigned h_pair = 0;                          // byte offset of the current chunk pair in a pixel
+    unsigned w_pair = 0;                          // byte offset of the current chunk pair in a weight row
+#pragma unroll
+    for (int q = 0; q < H_ITEMS; ++q) h_goff[q] *= 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b_goff[q] *= 4;
 
-    float4 rh0, rh1, rh2, rh3, rh4, rh5, rb0, rb1, rb2, rb3;
-#define MSR_LOAD_H()                                                                             \
+    float4 rh0, rh1, rh2, rh3, rh4, rh5;
+    float4 re0, re1, re2, re3;                    // weights of even K-steps in flight
+    float4 ro0, ro1, ro2, ro3;                    // weights of odd K-steps in flight
+#define MSR_BUFLD(rs, voff, soff) \
+    __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (int)(soff), 0))
+#define MSR_LOAD_H(soff)                                                                         \
     {                                                                                            \
-        rh0 = *reinterpret_cast<const float4*>(h_src + h_goff[0]);                               \
-        rh1 = *reinterpret_cast<const float4*>(h_src + h_goff[1]);                               \
-        rh2 = *reinterpret_cast<const float4*>(h_src + h_goff[2]);                               \
-        rh3 = *reinterpret_cast<const float4*>(h_src + h_goff[3]);                               \
-        rh4 = *reinterpret_cast<const float4*>(h_src + h_goff[4]);                               \
-        rh5 = *reinterpret_cast<const float4*>(h_src + h_goff[5]);                               \
+        rh0 = MSR_BUFLD(rs_in, h_goff[0], soff);                                                 \
+        rh1 = MSR_BUFLD(rs_in, h_goff[1], soff);                                                 \
+        rh2 = MSR_BUFLD(rs_in, h_goff[2], soff);                                                 \
+        rh3 = MSR_BUFLD(rs_in, h_goff[3], soff);                                                 \
+        rh4 = MSR_BUFLD(rs_in, h_goff[4], soff);                                                 \
+        rh5 = MSR_BUFLD(rs_in, h_goff[5], soff);                                                 \
     }
 #define MSR_WRITE_H()                                                                            \
     {                                                                                            \
@@ -663,24 +677,26 @@ conv_igemm_bf16x3_halo(const ConvParams p, const TileGeom g) {
         *reinterpret_cast<float4*>(Ah + h_loff[4]) = rh4;                                        \
         *reinterpret_cast<float4*>(Ah + h_loff[5]) = rh5;                                        \
     }
-#define MSR_LOAD_B(ptr)                                                                          \
+// weights of K-step U of the current pair (U = 18, 19 are the first two steps of the next pair)
+#define MSR_WPTR(U) (w_pair + ((U) / 9) * (BKC * 4) + (unsigned)((U) % 9) * w_tap_bytes)
+#define MSR_LOAD_B(R, soff)                                                                      \
     {                                                                                            \
-        rb0 = *reinterpret_cast<const float4*>((ptr) + b_goff[0]);                               \
-        rb1 = *reinterpret_cast<const float4*>((ptr) + b_goff[1]);                               \
-        rb2 = *reinterpret_cast<const float4*>((ptr) + b_goff[2]);                               \
-        rb3 = *reinterpret_cast<const float4*>((ptr) + b_goff[3]);                               \
+        R##0 = MSR_BUFLD(rs_wt, b_goff[0], soff);                                                \
+        R##1 = MSR_BUFLD(rs_wt, b_goff[1], soff);                                                \
+        R##2 = MSR_BUFLD(rs_wt, b_goff[2], soff);                                                \
+        R##3 = MSR_BUFLD(rs_wt, b_goff[3], soff);                                                \
     }
-#define MSR_WRITE_B(buf)                                                                         \
+#define MSR_WRITE_B(buf, R)                                                                      \
     {                                                                                            \
         float* b_ = Bs + (buf) * BN * BKP;                                                       \
-        *reinterpret_cast<float4*>(b_ + b_loff[0]) = rb0;                                        \
-        *reinterpret_cast<float4*>(b_ + b_loff[1]) = rb1;                                        \
-        *reinterpret_cast<float4*>(b_ + b_loff[2]) = rb2;                                        \
-        *reinterpret_cast<float4*>(b_ + b_loff[3]) = rb3;                                        \
+        *reinterpret_cast<float4*>(b_ + b_loff[0]) = R##0;                                       \
+        *reinterpret_cast<float4*>(b_ + b_loff[1]) = R##1;                                       \
+        *reinterpret_cast<float4*>(b_ + b_loff[2]) = R##2;                                       \
+        *reinterpret_cast<float4*>(b_ + b_loff[3]) = R##3;                                       \
     }
-#define MSR_COMPUTE(buf, TAPOFF)                                                                 \
+#define MSR_COMPUTE(buf, TAP)                                                                    \
     {                                                                                            \
-        const float* a_ = Ah + (TAPOFF);                                                         \
+        const float* a_ = Ah + (((TAP) / 3) * HW + ((TAP) % 3)) * BKP;                           \
         const float* b_ = Bs + (buf) * BN * BKP;                                                 \
         _Pragma("unroll") for (int kg = 0; kg < 2; ++kg) {                                       \
             bf16x8 ah[MT], al[MT], bh[NT], bl[NT];                                               \
@@ -701,51 +717,56 @@ conv_igemm_bf16x3_halo(const ConvParams p, const TileGeom g) {
             }                                                                                    \
         }                                                                                        \
     }
-// taps 0..7 of a chunk: prefetch the next tap's weights, compute, write them to the other buffer
-#define MSR_TAP(T)                                                                               \
+// K-step T (0..17, compile time) of a chunk pair.  Weights of step T+2 are requested into LD (the set that step
+// T's weights have just left), the MFMAs of step T run from LDS buffer T & 1, then the weights of step T+1 (set
+// WR, requested one step ago) go to the other buffer.  The halo of the next chunk is requested on tap 7 and
+// replaces the old one after tap 8.  LASTP (compile time) drops everything that would reach past the last pair,
+// so no load or LDS write sits under a run-time condition (hipcc would wait vmcnt(0) around those).
+#define MSR_STEP(T, LD, WR, LASTP)                                                               \
     {                                                                                            \
-        MSR_LOAD_B(b_src + (size_t)((T) + 1) * w_tap_stride);                                    \
+        if (!(LASTP) || (T) + 2 < 18) MSR_LOAD_B(LD, MSR_WPTR((T) + 2));                         \
+        if ((T) == 7) MSR_LOAD_H(h_pair + BKC * 4);                                              \
+        if ((T) == 16 && !(LASTP)) MSR_LOAD_H(h_pair + 2 * BKC * 4);                             \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        MSR_COMPUTE(cur, (((T) / 3) * HW + ((T) % 3)) * BKP);                                    \
+        MSR_COMPUTE((T) & 1, (T) % 9);                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        MSR_WRITE_B(cur ^ 1);                                                                    \
-        __syncthreads();                                                                         \
-        cur ^= 1;                                                                                \
+        if (!(LASTP) || (T) + 1 < 18) MSR_WRITE_B(((T) & 1) ^ 1, WR);                            \
+        if ((T) == 8 || ((T) == 17 && !(LASTP))) {                                               \
+            __syncthreads();            /* every wave is done with the old halo */               \
+            MSR_WRITE_H();                                                                       \
+        }                                                                                        \
+        if (!(LASTP) || (T) + 1 < 18) __syncthreads();                                           \
     }
+#define MSR_PAIR(LASTP)                                                                          \
+    MSR_STEP(0, re, ro, LASTP) MSR_STEP(1, ro, re, LASTP) MSR_STEP(2, re, ro, LASTP)             \
+    MSR_STEP(3, ro, re, LASTP) MSR_STEP(4, re, ro, LASTP) MSR_STEP(5, ro, re, LASTP)             \
+    MSR_STEP(6, re, ro, LASTP) MSR_STEP(7, ro, re, LASTP) MSR_STEP(8, re, ro, LASTP)             \
+    MSR_STEP(9, ro, re, LASTP) MSR_STEP(10, re, ro, LASTP) MSR_STEP(11, ro, re, LASTP)           \
+    MSR_STEP(12, re, ro, LASTP) MSR_STEP(13, ro, re, LASTP) MSR_STEP(14, re, ro, LASTP)          \
+    MSR_STEP(15, ro, re, LASTP) MSR_STEP(16, re, ro, LASTP) MSR_STEP(17, ro, re, LASTP)
 
-    MSR_LOAD_H();
-    MSR_LOAD_B(b_src);
+    // prologue: halo of chunk 0 and the weights of step 0 into LDS, the weights of step 1 stay in flight
+    MSR_LOAD_H(h_pair);
+    MSR_LOAD_B(re, MSR_WPTR(0));
+    MSR_LOAD_B(ro, MSR_WPTR(1));
     MSR_WRITE_H();
-    MSR_WRITE_B(0);
+    MSR_WRITE_B(0, re);
     __syncthreads();
-    int cur = 0;
-    for (int cc = 0; cc < chunks; ++cc) {
-        MSR_TAP(0) MSR_TAP(1) MSR_TAP(2) MSR_TAP(3) MSR_TAP(4) MSR_TAP(5) MSR_TAP(6) MSR_TAP(7)
-        // tap 8: the seam.  Prefetch the next chunk's halo and its tap-0 weights (if any).
-        const bool more = cc + 1 < chunks;
-        if (more) {
-            h_src += BKC;
-            b_src += BKC;
-            MSR_LOAD_H();
-            MSR_LOAD_B(b_src);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        MSR_COMPUTE(cur, (2 * HW + 2) * BKP);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) {
-            __syncthreads();            // every wave is done with the old halo
-            MSR_WRITE_H();
-            MSR_WRITE_B(cur ^ 1);
-            __syncthreads();
-            cur ^= 1;
-        }
+    for (int pr = 0; pr < chunks / 2 - 1; ++pr) {
+        MSR_PAIR(false)
+        h_pair += 2 * BKC * 4;
+        w_pair += 2 * BKC * 4;
     }
+    MSR_PAIR(true)
+#undef MSR_BUFLD
 #undef MSR_LOAD_H
 #undef MSR_WRITE_H
+#undef MSR_WPTR
 #undef MSR_LOAD_B
 #undef MSR_WRITE_B
 #undef MSR_COMPUTE
-#undef MSR_TAP
+#undef MSR_STEP
+#undef MSR_PAIR
 
     conv_epilogue<WM, WN, MT, NT, EPI>(p, g, acc, 0, wm, wn, half, l31, n0, tx0, ty0, b0);
 }
@@ -986,7 +1007,8 @@ static hipError_t launch_bf16x3(const ConvParams& p, int epi, hipStream_t s) {
 static hipError_t launch_halo(const ConvParams& p, int epi, hipStream_t s) {
     TileGeom g;
     if (!make_geom(p, 128, 128, 32, g)) return hipErrorInvalidValue;
-    if (g.tb != 1 || g.th_l != 3 || g.tw_l != 4 || p.stride != 1 || p.KH != 3 || p.KW != 3 || p.ksplit > 1)
+    if (g.tb != 1 || g.th_l != 3 || g.tw_l != 4 || p.stride != 1 || p.KH != 3 || p.KW != 3 || p.ksplit > 1 ||
+        p.Cin % 64)   // the K loop is unrolled by two steps: 9 * (Cin / 32) must be even
         return hipErrorInvalidValue;
     switch (epi) {
         case EPI_BIAS: conv_igemm_bf16x3_halo<EPI_BIAS><<<g.tiles_mn, 256, HALO_LDS, s>>>(p, g); break;
