@@ -928,8 +928,9 @@ int conv_pick_tile(int M, int N, int epilogue, int prec) {
     // Measured on MI355X (tests/gpu_conv_bench.py): the 16-channel K-step (3 workgroups per CU) is ~8 % faster
     // than the 32-channel one for the SPADE epilogue (its long epilogue is covered by a third resident
     // workgroup) and ~3 % slower for plain long-K convs.
+    // At bf16 rates the 128 x 128 tile is 1.6x as efficient as the 64 x 64 one, so one workgroup per CU is enough.
     const long big_blocks = (long)((M + 127) / 128) * (N / 128);
-    if (N % 128 == 0 && big_blocks >= 512)
+    if (N % 128 == 0 && big_blocks >= (prec == PREC_BF16X3 ? 256 : 512))
         return (epilogue == EPI_SPADE && prec == PREC_F32) ? TILE_128x128_K16 : TILE_128x128;
     return TILE_64x64;
 }

@@ -12,8 +12,8 @@ import sys
 
 def family(name: str) -> str:
     name = name.split("(")[0]
-    if "conv_igemm_f32" in name:
-        return "conv_igemm_f32"
+    if "conv_igemm" in name or "splitk_epilogue" in name:
+        return "conv_igemm"      # every instantiation of the implicit-GEMM conv (+ its split-K epilogue)
     return name.replace("void ", "").replace("msr::", "").split("<")[0]
 
 
