@@ -49,15 +49,107 @@ struct TileGeom {
 
 // ------------------------------------------------------------------------------------------------------
 // Epilogue shared by the fp32 and the split-bf16 kernels.
+// C/D map of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
+// Per m-tile the 16 rows a lane owns are handled in two phases — (1) addresses and ALL global loads (the tensor
+// being normalised / the residual), (2) arithmetic and stores — so the loads of a tile are in flight together
+// instead of one load-wait-use chain per row.  Rows outside the batch read a clamped (valid) address and are
+// only masked at the store.
 // ------------------------------------------------------------------------------------------------------
-template <int WM, int WN, int MT, int NT, int EPI>
+__device__ __forceinline__ unsigned lane_xor1(unsigned v) {
+    // neighbour exchange lane <-> lane ^ 1 in the VALU (DPP quad_perm [1,0,3,2]), no LDS crossbar
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+}
+
+template <int WM, int WN, int MT, int NT, int EPI, bool SPLIT, int RB>
+__device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, const TileGeom& g, f32x16 (&acc)[MT][NT],
+                                                   int wm, int wn, int half, int l31, int n0, int tx0, int ty0,
+                                                   int b0) {
+    const int twm = (1 << g.tw_l) - 1, thm = (1 << g.th_l) - 1;
+    constexpr int NCH = EPI == EPI_SPADE ? NT / 2 : NT;
+    float cb0[NCH], cb1[NCH], cmean[NCH], cstd[NCH];
+    int ccol[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        if constexpr (EPI == EPI_SPADE) {
+            const int colg = n0 + (wn * NT + 2 * j) * 32 + l31;   // gamma column; its beta twin is +32
+            ccol[j] = (n0 + wn * NT * 32) / 2 + j * 32 + l31;    // channel
+            cb0[j] = p.bias[colg];
+            cb1[j] = p.bias[colg + 32];
+            cmean[j] = p.mean[ccol[j]];
+            cstd[j] = SPLIT ? 1.f / p.stdv[ccol[j]] : p.stdv[ccol[j]];   // bf16x3: multiply by 1/sigma
+        } else {
+            ccol[j] = n0 + (wn * NT + j) * 32 + l31;
+            cb0[j] = p.bias[ccol[j]];
+            cb1[j] = cmean[j] = cstd[j] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int mr = 0; mr < MT * (16 / RB); ++mr) {
+        const int m = mr / (16 / RB), r0 = (mr % (16 / RB)) * RB;   // RB rows of m-tile m per batch
+        int ooff[RB];
+        bool ok[RB];
+        float xin[RB][NCH];
+        // phase 1: addresses and loads
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            const int r = r0 + q;
+            const int row = (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int tx = row & twm, ty = (row >> g.tw_l) & thm, tbi = row >> (g.tw_l + g.th_l);
+            int bb = b0 + tbi;
+            ok[q] = tbi < g.tb && bb < p.B;
+            bb = bb < p.B ? bb : p.B - 1;
+            const int y = ty0 + ty, x = tx0 + tx;
+            ooff[q] = p.out_off + bb * p.out_pb + y * p.out_py + x * p.out_px;
+            if constexpr (EPI == EPI_SPADE || EPI == EPI_RES) {
+                const float* arow = p.aux + (size_t)bb * p.aux_pb + (y >> p.aux_shift) * p.aux_py +
+                                    (x >> p.aux_shift) * p.aux_px;
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) xin[q][j] = arow[ccol[j]];
+            }
+        }
+        // phase 2: arithmetic and stores
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            const int r = r0 + q;
+            float* orow = p.out + ooff[q];
+            if constexpr (EPI == EPI_SPADE) {
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
+                    const float gam = acc[m][2 * j][r] + cb0[j];
+                    const float bet = acc[m][2 * j + 1][r] + cb1[j];
+                    const float normalized = SPLIT ? (xin[q][j] - cmean[j]) * cstd[j] : (xin[q][j] - cmean[j]) / cstd[j];
+                    float v = gam * normalized + bet;
+                    v = v >= 0.f ? v : v * p.slope;
+                    if constexpr (SPLIT) {
+                        // lanes 0..31 of a half-wave hold the 32 channels of ONE chunk of this pixel: pair up
+                        // neighbouring lanes so that every lane still issues one 4-byte store
+                        unsigned hi, lo;
+                        msr_split_bf16(v, hi, lo);
+                        const unsigned nhi = lane_xor1(hi), nlo = lane_xor1(lo);
+                        unsigned* chunk = reinterpret_cast<unsigned*>(orow) + (ccol[j] & ~31);
+                        const unsigned word = (l31 & 1) ? (nlo | (lo << 16)) : (hi | (nhi << 16));
+                        if (ok[q]) chunk[((l31 & 1) ? 16 : 0) + (l31 >> 1)] = word;
+                    } else {
+                        if (ok[q]) orow[ccol[j]] = v;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    float v = acc[m][n][r] + cb0[n];
+                    if constexpr (EPI == EPI_RES) v += xin[q][n];
+                    if (ok[q]) orow[ccol[n]] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int MT, int NT, int EPI, int RB = 16>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileGeom& g, f32x16 (&acc)[MT][NT], int ks,
                                               int wm, int wn, int half, int l31, int n0, int tx0, int ty0, int b0) {
-    const int twm = (1 << g.tw_l) - 1, thm = (1 << g.th_l) - 1;
-    // ---- epilogue -----------------------------------------------------------------------------------
-    // C/D map of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
-    // Per-column constants (bias, SPADE mean / std) are loaded once, before the row loops.
     if constexpr (EPI == EPI_PARTIAL) {
+        const int twm = (1 << g.tw_l) - 1, thm = (1 << g.th_l) - 1;
         float* pbase = p.partial + (size_t)ks * ((size_t)p.B * p.Hout * p.Wout * p.N);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -72,72 +164,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileGeo
                 for (int n = 0; n < NT; ++n) orow[n0 + (wn * NT + n) * 32 + l31] = acc[m][n][r];
             }
         }
-        return;
-    }
-    constexpr int NCH = EPI == EPI_SPADE ? NT / 2 : NT;
-    float cb0[NCH], cb1[NCH], cmean[NCH], cstd[NCH];
-    int ccol[NCH];
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        if constexpr (EPI == EPI_SPADE) {
-            const int colg = n0 + (wn * NT + 2 * j) * 32 + l31;   // gamma column; its beta twin is +32
-            ccol[j] = (n0 + wn * NT * 32) / 2 + j * 32 + l31;    // channel
-            cb0[j] = p.bias[colg];
-            cb1[j] = p.bias[colg + 32];
-            cmean[j] = p.mean[ccol[j]];
-            cstd[j] = p.stdv[ccol[j]];
-        } else {
-            ccol[j] = n0 + (wn * NT + j) * 32 + l31;
-            cb0[j] = p.bias[ccol[j]];
-            cb1[j] = cmean[j] = cstd[j] = 0.f;
-        }
-    }
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int tx = row & twm, ty = (row >> g.tw_l) & thm, tbi = row >> (g.tw_l + g.th_l);
-            const int bb = b0 + tbi;
-            if (tbi >= g.tb || bb >= p.B) continue;
-            const int y = ty0 + ty, x = tx0 + tx;
-            float* orow = p.out + (size_t)p.out_off + (size_t)bb * p.out_pb + y * p.out_py + x * p.out_px;
-            if constexpr (EPI == EPI_SPADE) {
-                const float* xrow = p.aux + (size_t)bb * p.aux_pb + (y >> p.aux_shift) * p.aux_py +
-                                    (x >> p.aux_shift) * p.aux_px;
-#pragma unroll
-                for (int j = 0; j < NCH; ++j) {
-                    const float gam = acc[m][2 * j][r] + cb0[j];
-                    const float bet = acc[m][2 * j + 1][r] + cb1[j];
-                    const float normalized = (xrow[ccol[j]] - cmean[j]) / cstd[j];
-                    float v = gam * normalized + bet;
-                    v = v >= 0.f ? v : v * p.slope;
-                    if (p.out_split) {
-                        // lanes 0..31 of a half-wave hold the 32 channels of ONE chunk of this pixel: pair up
-                        // neighbouring lanes so that every lane still issues one 4-byte store
-                        unsigned hi, lo;
-                        msr_split_bf16(v, hi, lo);
-                        const unsigned nhi = __shfl_xor(hi, 1), nlo = __shfl_xor(lo, 1);
-                        unsigned* chunk = reinterpret_cast<unsigned*>(orow) + (ccol[j] & ~31);
-                        if (l31 & 1) chunk[16 + (l31 >> 1)] = nlo | (lo << 16);
-                        else chunk[l31 >> 1] = hi | (nhi << 16);
-                    } else {
-                        orow[ccol[j]] = v;
-                    }
-                }
-            } else {
-                const float* rrow = nullptr;
-                if constexpr (EPI == EPI_RES)
-                    rrow = p.aux + (size_t)bb * p.aux_pb + (y >> p.aux_shift) * p.aux_py +
-                           (x >> p.aux_shift) * p.aux_px;
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    float v = acc[m][n][r] + cb0[n];
-                    if constexpr (EPI == EPI_RES) v += rrow[ccol[n]];
-                    orow[ccol[n]] = v;
-                }
-            }
-        }
+    } else if constexpr (EPI == EPI_SPADE) {
+        if (p.out_split) conv_epilogue_body<WM, WN, MT, NT, EPI, true, RB>(p, g, acc, wm, wn, half, l31, n0, tx0, ty0, b0);
+        else conv_epilogue_body<WM, WN, MT, NT, EPI, false, RB>(p, g, acc, wm, wn, half, l31, n0, tx0, ty0, b0);
+    } else {
+        conv_epilogue_body<WM, WN, MT, NT, EPI, false, RB>(p, g, acc, wm, wn, half, l31, n0, tx0, ty0, b0);
     }
 }
 
@@ -371,7 +402,8 @@ conv_igemm(const ConvParams p, const TileGeom g) {
 #undef MSR_WRITE_LDS
 #undef MSR_COMPUTE
 
-    conv_epilogue<WM, WN, MT, NT, EPI>(p, g, acc, ks, wm, wn, half, l31, n0, tx0, ty0, b0);
+    // the 16-channel K-step variant must stay under 168 VGPRs (3 workgroups per CU): small load batches there
+    conv_epilogue<WM, WN, MT, NT, EPI, (BKC == 16 ? 4 : 16)>(p, g, acc, ks, wm, wn, half, l31, n0, tx0, ty0, b0);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -19,7 +19,7 @@ for i, f in enumerate(GEN_FILTERS, start=1):
         plan.append((f"rb{i}.gb3", r, 128, 2 * cin)); plan.append((f"rb{i}.conv3", r, cin, f))
     plan.append((f"rb{i}.gb2", r, 128, 2 * f)); plan.append((f"rb{i}.conv2", r, f, f))
     cin = f
-rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"]]   # split-K epilogues excluded
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 n = len(plan)
 calls = len(rows) // n
@@ -30,6 +30,6 @@ for (name, r, ci, N), row in zip(plan, last):
     ms = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
     fl = 2.0 * B * r * r * ci * N * 9
     tot_ms += ms; tot_fl += fl
-    k = row["Kernel_Name"].split("<")[1].split(">")[0]
-    print(f"{name:14s} {r:4d} {ci:5d} {N:5d} {int(row['Grid_Size_X'])//int(row['Workgroup_Size_X']):7d} {row['Workgroup_Size_X']:>4s} {ms:8.3f} {fl/ms/1e9:7.1f}  <{k}>")
+    k = row["Kernel_Name"].split("(")[0].replace("void msr::", "")
+    print(f"{name:14s} {r:4d} {ci:5d} {N:5d} {int(row['Grid_Size_X'])//int(row['Workgroup_Size_X']):7d} {row['Workgroup_Size_X']:>4s} {ms:8.3f} {fl/ms/1e9:7.1f}  {k}")
 print(f"total conv {tot_ms:.2f} ms, {tot_fl/1e9:.1f} GFLOP, {tot_fl/tot_ms/1e9:.1f} TF/s")
