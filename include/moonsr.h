@@ -121,6 +121,10 @@ int msr_stitch_tile(msr_handle* h, const float* pred_dev, const int32_t* key_dev
  * host passes NumPy's own evaluation so the GPU stitcher is bit-identical to the NumPy reference. */
 int msr_set_blend_window(msr_handle* h, const double* host_window, int32_t side);
 
+/* CRC-32C (Castagnoli) of a HOST buffer, continuing from `crc` (0 to start).  Host-only helper of the TensorBundle
+ * weight reader (moonsuperresolution_amd/tf_checkpoint.py): checkpoint data and index blocks carry masked CRC-32C. */
+uint32_t msr_crc32c(const void* host_data, uint64_t n, uint32_t crc);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 typedef struct {
     char name[48];        /* kernel family, e.g. "conv_igemm_f32" */

@@ -292,6 +292,35 @@ extern "C" {
 
 int msr_abi_version(void) { return MSR_ABI_VERSION; }
 
+uint32_t msr_crc32c(const void* host_data, uint64_t n, uint32_t crc) {
+    static uint32_t table[8][256];
+    static bool ready = false;
+    if (!ready) {   // slicing-by-8 tables, reflected polynomial 0x82F63B78
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            table[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xFF];
+        ready = true;
+    }
+    const uint8_t* p = static_cast<const uint8_t*>(host_data);
+    uint32_t c = crc ^ 0xFFFFFFFFu;
+    while (n >= 8) {
+        uint32_t lo, hi;
+        std::memcpy(&lo, p, 4);
+        std::memcpy(&hi, p + 4, 4);
+        lo ^= c;
+        c = table[7][lo & 0xFF] ^ table[6][(lo >> 8) & 0xFF] ^ table[5][(lo >> 16) & 0xFF] ^ table[4][lo >> 24] ^
+            table[3][hi & 0xFF] ^ table[2][(hi >> 8) & 0xFF] ^ table[1][(hi >> 16) & 0xFF] ^ table[0][hi >> 24];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) c = table[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+
 const char* msr_last_error(const msr_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 int msr_create(const msr_config* cfg, msr_handle** out) {

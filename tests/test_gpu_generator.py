@@ -184,3 +184,21 @@ def test_bf16x3_precision_within_tolerance(Generator):
     gen.close()
     with pytest.raises(ValueError):
         Generator(64, 2, precision="fp8")
+
+
+def test_load_GAN_model_from_savedmodel_dirs(Generator, tmp_path):
+    """process_full_tiles.py:13-31: load_GAN_model(path, image_size, batch_size) with path+'generator' / path+'encoder'."""
+    from moonsuperresolution_amd import load_GAN_model, tf_checkpoint
+    from tests.test_tf_checkpoint import _keras_keys
+    w = make_weights("gaugan", 64, seed=1234, bias_scale=0.05)
+    gen_keys, enc_keys = _keras_keys(w)
+    root = str(tmp_path) + "/"
+    tf_checkpoint.write_tensor_bundle(root + "generator/variables/variables", gen_keys)
+    tf_checkpoint.write_tensor_bundle(root + "encoder/variables/variables", enc_keys)
+    gen = load_GAN_model(root, 64, 2, eps=make_latent_noise(2, 256, 7))
+    y = gen(synthetic_patches(2, 64, 0))
+    g = np.load(os.path.join(GOLD, "spade64_gaugan.npz"))
+    assert rel_linf(y, g["output"]) <= TOL
+    gen.close()
+    with pytest.raises(AssertionError):
+        load_GAN_model(root + "missing/", 64, 2)
