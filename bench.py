@@ -112,10 +112,18 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    # Rehearsal knobs (one-GPU boxes only): MSR_BENCH_DEVICE pins every rank to one device and MSR_BENCH_BACKEND=gloo
+    # replaces RCCL, so the N>1 plumbing can be exercised without N GPUs.  The driver's runs set neither.
+    if "MSR_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["MSR_BENCH_DEVICE"])
     torch.cuda.set_device(local)
+    backend = os.environ.get("MSR_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from moonsuperresolution_amd import Generator, make_latent_noise, make_weights, synthetic_patches
 
@@ -146,7 +154,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     step_ms = [a.elapsed_time(b) for a, b in ev]

@@ -127,7 +127,7 @@ def test_spade256_against_oracle(Generator):
 
 def test_full_size_configs_properties(Generator):
     """BASELINE configs 2 and 3 at full batch: size-independent properties (the oracle would take minutes)."""
-    for S, B in ((256, 16), (512, 8)):
+    for S, B in ((256, 16), (512, 8), (512, 12)):      # (512, 12) = the production setting of run_GAN.sh:24-26
         gen = Generator(S, B, variant="gaugan", weights=1234, eps=7)
         x = torch.from_numpy(synthetic_patches(B, S, 11)).cuda()
         a = gen.forward_device(x).clone()
