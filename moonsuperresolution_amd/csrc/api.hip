@@ -25,7 +25,7 @@ struct WeightSpec {
     bool loaded = false;
 };
 
-enum OpType { OP_CONV, OP_SMALLCIN, OP_MOMENTS, OP_NORMACT, OP_DENSE, OP_LATENT, OP_HEAD, OP_DIRECT };
+enum OpType { OP_CONV, OP_SMALLCIN, OP_MOMENTS, OP_MOMENTS_SLABS, OP_NORMACT, OP_DENSE, OP_LATENT, OP_HEAD, OP_DIRECT };
 enum Family { FAM_CONV = 0, FAM_SMALLCIN, FAM_MOMENTS, FAM_NORMACT, FAM_DENSE, FAM_LATENT, FAM_HEAD, FAM_DIRECT,
               FAM_COUNT };
 const char* kFamilyName[FAM_COUNT] = {"conv_igemm", "conv_smallcin", "moments", "norm_act", "dense",
@@ -40,6 +40,7 @@ struct Op {
     hipEvent_t done = nullptr;        // recorded on the auxiliary stream after an on_aux op
     hipEvent_t wait = nullptr;        // the main stream waits for this before launching the op
     ConvParams conv{}; int epi = 0, tile = 0;
+    int stat_slabs = 0;               // > 0: the conv's epilogue also writes partial output moments (fused)
     SmallCinParams sc{};
     struct { const float* x; int G, P, C; float eps; float* mean; float* stdv; } mom{};
     NormActParams na{};
@@ -71,6 +72,8 @@ struct msr_handle {
     float* dense_partial = nullptr;
     float* conv_partial = nullptr;     // split-K workspace [ksplit][M][N]
     size_t conv_partial_floats = 0;
+    float* stat_ws = nullptr;          // fused-moments slabs [P][3][N] of the conv that ran last
+    size_t stat_ws_floats = 0;
     float* z = nullptr;
     // tiler
     double* window = nullptr;     // [S-2p, S-2p] float64
@@ -369,6 +372,7 @@ int msr_destroy(msr_handle* h) {
     if (h->mom_partial) hipFree(h->mom_partial);
     if (h->dense_partial) hipFree(h->dense_partial);
     if (h->conv_partial) hipFree(h->conv_partial);
+    if (h->stat_ws) hipFree(h->stat_ws);
     if (h->window) hipFree(h->window);
     if (h->stitch_grid) hipFree(h->stitch_grid);
     for (auto e : h->ev_pool) hipEventDestroy(e);
@@ -687,7 +691,7 @@ int plan_spade(msr_handle* h) {
         // one SPADE layer + its consumer conv:  a = lrelu(SPADE(x)) ; y = conv(a)
         auto spade_then_conv = [&](int j, const float* x, int rx, int xshift, int C, const float* mean,
                                    const float* stdv, int conv_idx, float* y, int epi, const float* res, int res_r,
-                                   int res_shift) -> int {
+                                   int res_shift, bool want_stats) -> int {
             char k[160];
             Padded hb, ab;
             snprintf(k, sizeof k, "ws.gen.rb%d.h%d", i, j); int rc2 = alloc_padded(h, k, r, 128, &hb); if (rc2) return rc2;
@@ -719,25 +723,37 @@ int plan_spade(msr_handle* h) {
             Op cv = conv_op(ab, cw, cb, B, r, f, 1, epi, h->prec);
             set_out_dense(cv.conv, y, r, f);
             if (epi == EPI_RES) set_aux_dense(cv.conv, res, res_r, f, res_shift);
+            // fused output moments (the tensor feeds a SPADE layer) unless the layer runs split-K
+            if (want_stats && cv.conv.ksplit == 1) cv.stat_slabs = conv_stat_slabs(cv.conv, cv.tile);
             h->ops.push_back(cv);
             return MSR_OK;
         };
+        // moments of a conv output: finalize the conv's own slabs if it emitted them, else read the tensor
+        auto push_moments = [&](const float* x, int P, int C, float* mean, float* stdv) {
+            const Op& last = h->ops.back();
+            if (last.type == OP_CONV && last.stat_slabs > 0) {
+                Op op; op.type = OP_MOMENTS_SLABS;
+                op.mom = {nullptr, 1, last.stat_slabs, C, 1e-5f, mean, stdv};
+                h->ops.push_back(op);
+            } else {
+                h->ops.push_back(moments_op(x, 1, P, C, 1e-5f, mean, stdv));
+                mom_need(1, P, C);
+            }
+        };
         // x1 = conv_1(lrelu(spade_1(x)))                                   blocks.py:29-30
-        rc = spade_then_conv(1, x_prev, r_prev, shift, cin, st_mean, st_std, 1, x1, EPI_BIAS, nullptr, 0, 0); if (rc) return rc;
-        h->ops.push_back(moments_op(x1, 1, B * r * r, f, 1e-5f, m1, s1));
-        mom_need(1, B * r * r, f);
+        rc = spade_then_conv(1, x_prev, r_prev, shift, cin, st_mean, st_std, 1, x1, EPI_BIAS, nullptr, 0, 0, true); if (rc) return rc;
+        push_moments(x1, B * r * r, f, m1, s1);
         if (learned) {
             // skip = conv_3(lrelu(spade_3(x)))                             blocks.py:33-34
-            rc = spade_then_conv(3, x_prev, r_prev, shift, cin, st_mean, st_std, 3, skip, EPI_BIAS, nullptr, 0, 0); if (rc) return rc;
+            rc = spade_then_conv(3, x_prev, r_prev, shift, cin, st_mean, st_std, 3, skip, EPI_BIAS, nullptr, 0, 0, false); if (rc) return rc;
             // out = skip + conv_2(lrelu(spade_2(x1)))                      blocks.py:31-32,38
-            rc = spade_then_conv(2, x1, r, 0, f, m1, s1, 2, outb, EPI_RES, skip, r, 0); if (rc) return rc;
+            rc = spade_then_conv(2, x1, r, 0, f, m1, s1, 2, outb, EPI_RES, skip, r, 0, true); if (rc) return rc;
         } else {
             // out = x + conv_2(lrelu(spade_2(x1))), x read through the folded up-sample
-            rc = spade_then_conv(2, x1, r, 0, f, m1, s1, 2, outb, EPI_RES, x_prev, r_prev, shift); if (rc) return rc;
+            rc = spade_then_conv(2, x1, r, 0, f, m1, s1, 2, outb, EPI_RES, x_prev, r_prev, shift, true); if (rc) return rc;
         }
         // moments of the block output == moments of its nearest-2x up-sample (every value is repeated 4x)
-        h->ops.push_back(moments_op(outb, 1, B * r * r, f, 1e-5f, mo, so));
-        mom_need(1, B * r * r, f);
+        push_moments(outb, B * r * r, f, mo, so);
         x_prev = outb; r_prev = r; cin = f; st_mean = mo; st_std = so;
     }
     {
@@ -746,6 +762,7 @@ int plan_spade(msr_handle* h) {
         hd.flops = 2.0 * B * S * S * 16.0 * 128;
         h->ops.push_back(hd);
     }
+    mom_doubles = std::max<size_t>(mom_doubles, (size_t)32 * 3 * 1024);   // also the slab-group scratch
     HIPCHK(h, hipMalloc(&h->mom_partial, std::max<size_t>(mom_doubles, 16) * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->dense_partial, std::max<size_t>(dense_part, 16) * sizeof(float)));
     h->total_bytes += mom_doubles * sizeof(double) + dense_part * sizeof(float);
@@ -863,13 +880,22 @@ int ensure_plan(msr_handle* h) {
     int rc = h->variant == MSR_PIX2PIX ? plan_pix2pix(h) : plan_spade(h);
     if (rc) return rc;
     h->fwd_flops = 0;
-    size_t need = 0;
+    size_t need = 0, stat_need = 0;
     for (auto& op : h->ops) {
         h->fwd_flops += op.flops;
         if (op.type == OP_CONV && op.conv.ksplit > 1)
             need = std::max(need, (size_t)op.conv.ksplit * op.conv.B * op.conv.Hout * op.conv.Wout * op.conv.N);
+        if (op.type == OP_CONV && op.stat_slabs > 0)
+            stat_need = std::max(stat_need, (size_t)op.stat_slabs * 3 * op.conv.N);
     }
     { int rc2 = ensure_conv_partial(h, need); if (rc2) return rc2; }
+    if (stat_need > h->stat_ws_floats) {
+        if (h->stat_ws) HIPCHK(h, hipFree(h->stat_ws));
+        h->stat_ws = nullptr;
+        HIPCHK(h, hipMalloc(&h->stat_ws, stat_need * sizeof(float)));
+        h->total_bytes += (stat_need - h->stat_ws_floats) * sizeof(float);
+        h->stat_ws_floats = stat_need;
+    }
     HIPCHK(h, hipDeviceSynchronize());
     h->planned = true;
     return MSR_OK;
@@ -932,6 +958,7 @@ int msr_forward(msr_handle* h, const float* in_dev, const float* eps_dev, float*
                 fam = FAM_CONV;
                 ConvParams cp = op.conv;
                 cp.partial = h->conv_partial;
+                cp.stat_partial = op.stat_slabs > 0 ? h->stat_ws : nullptr;
                 e = launch_conv_igemm(cp, op.epi, op.tile, s);
                 break;
             }
@@ -946,6 +973,11 @@ int msr_forward(msr_handle* h, const float* in_dev, const float* eps_dev, float*
                 fam = FAM_MOMENTS;
                 e = launch_moments(op.mom.x, op.mom.G, op.mom.P, op.mom.C, op.mom.eps, h->mom_partial, op.mom.mean,
                                    op.mom.stdv, s);
+                break;
+            case OP_MOMENTS_SLABS:
+                fam = FAM_MOMENTS;
+                e = launch_moments_from_slabs(h->stat_ws, op.mom.P, op.mom.C, op.mom.eps, h->mom_partial, op.mom.mean,
+                                              op.mom.stdv, s);
                 break;
             case OP_NORMACT: fam = FAM_NORMACT; e = launch_norm_act(op.na, s); break;
             case OP_DENSE:

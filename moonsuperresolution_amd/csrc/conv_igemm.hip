@@ -63,7 +63,7 @@ __device__ __forceinline__ unsigned lane_xor1(unsigned v) {
 template <int WM, int WN, int MT, int NT, int EPI, bool SPLIT, int RB>
 __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, const TileGeom& g, f32x16 (&acc)[MT][NT],
                                                    int wm, int wn, int half, int l31, int n0, int tx0, int ty0,
-                                                   int b0) {
+                                                   int b0, int stat_tile) {
     const int twm = (1 << g.tw_l) - 1, thm = (1 << g.th_l) - 1;
     constexpr int NCH = EPI == EPI_SPADE ? NT / 2 : NT;
     float cb0[NCH], cb1[NCH], cmean[NCH], cstd[NCH];
@@ -83,6 +83,10 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, const Ti
             cb1[j] = cmean[j] = cstd[j] = 0.f;
         }
     }
+    // fused output moments (EPI_BIAS / EPI_RES): shifted sums per lane and column, shift = the lane's first value
+    float st_v0[NT], st_s1[NT], st_s2[NT], st_n = 0.f;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) st_v0[n] = st_s1[n] = st_s2[n] = 0.f;
 #pragma unroll
     for (int mr = 0; mr < MT * (16 / RB); ++mr) {
         const int m = mr / (16 / RB), r0 = (mr % (16 / RB)) * RB;   // RB rows of m-tile m per batch
@@ -139,6 +143,37 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, const Ti
                     float v = acc[m][n][r] + cb0[n];
                     if constexpr (EPI == EPI_RES) v += xin[q][n];
                     if (ok[q]) orow[ccol[n]] = v;
+                    if (mr == 0 && q == 0) st_v0[n] = v;
+                    const float d = ok[q] ? v - st_v0[n] : 0.f;
+                    st_s1[n] += d;
+                    st_s2[n] += d * d;
+                }
+                st_n += ok[q] ? 1.f : 0.f;
+            }
+        }
+    }
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_RES) {
+        if (p.stat_partial) {
+            // lane -> (count, mean, M2); lanes l and l ^ 32 hold the same columns for different rows: Chan-combine
+            const int slab = (stat_tile * WM + wm);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const float cnt = st_n;
+                const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+                float mean = st_v0[n] + st_s1[n] * inv;
+                float m2 = st_s2[n] - st_s1[n] * st_s1[n] * inv;
+                const float ocnt = __shfl_xor(cnt, 32), omean = __shfl_xor(mean, 32), om2 = __shfl_xor(m2, 32);
+                const float tot = cnt + ocnt;
+                if (tot > 0.f) {
+                    const float delta = omean - mean;
+                    m2 = m2 + om2 + delta * delta * (cnt * ocnt / tot);
+                    mean = mean + delta * (ocnt / tot);
+                }
+                if (half == 0) {
+                    float* o = p.stat_partial + (size_t)slab * 3 * p.N + ccol[n];
+                    o[0] = tot;
+                    o[p.N] = mean;
+                    o[2 * p.N] = m2 > 0.f ? m2 : 0.f;
                 }
             }
         }
@@ -148,6 +183,8 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, const Ti
 template <int WM, int WN, int MT, int NT, int EPI, int RB = 16>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileGeom& g, f32x16 (&acc)[MT][NT], int ks,
                                               int wm, int wn, int half, int l31, int n0, int tx0, int ty0, int b0) {
+    // m-tile index of this workgroup (slab row of the fused output moments)
+    const int stat_tile = ((b0 / g.tb) * g.tiles_y + (ty0 >> g.th_l)) * g.tiles_x + (tx0 >> g.tw_l);
     if constexpr (EPI == EPI_PARTIAL) {
         const int twm = (1 << g.tw_l) - 1, thm = (1 << g.th_l) - 1;
         float* pbase = p.partial + (size_t)ks * ((size_t)p.B * p.Hout * p.Wout * p.N);
@@ -165,10 +202,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileGeo
             }
         }
     } else if constexpr (EPI == EPI_SPADE) {
-        if (p.out_split) conv_epilogue_body<WM, WN, MT, NT, EPI, true, RB>(p, g, acc, wm, wn, half, l31, n0, tx0, ty0, b0);
-        else conv_epilogue_body<WM, WN, MT, NT, EPI, false, RB>(p, g, acc, wm, wn, half, l31, n0, tx0, ty0, b0);
+        if (p.out_split) conv_epilogue_body<WM, WN, MT, NT, EPI, true, RB>(p, g, acc, wm, wn, half, l31, n0, tx0, ty0, b0, stat_tile);
+        else conv_epilogue_body<WM, WN, MT, NT, EPI, false, RB>(p, g, acc, wm, wn, half, l31, n0, tx0, ty0, b0, stat_tile);
     } else {
-        conv_epilogue_body<WM, WN, MT, NT, EPI, false, RB>(p, g, acc, wm, wn, half, l31, n0, tx0, ty0, b0);
+        conv_epilogue_body<WM, WN, MT, NT, EPI, false, RB>(p, g, acc, wm, wn, half, l31, n0, tx0, ty0, b0, stat_tile);
     }
 }
 
@@ -953,6 +990,75 @@ static bool make_geom(const ConvParams& p, int BM, int BN, int BKC, TileGeom& g)
     g.tiles_n = p.N / BN;
     g.tiles_mn = g.tiles_x * g.tiles_y * g.tiles_b * g.tiles_n;
     return true;
+}
+
+int conv_stat_slabs(const ConvParams& p, int tile) {
+    const int bm = tile == TILE_64x64 ? 64 : 128, wm = 2;
+    TileGeom g;
+    if (!make_geom(p, bm, bm, tile == TILE_128x128_K16 ? 16 : 32, g)) return 0;
+    return g.tiles_x * g.tiles_y * g.tiles_b * wm;
+}
+
+// Stage 1: grid (C/32, groups): 32 slab slots x 32 channels per workgroup, sequential Chan per slot over the
+// group's slab range, fixed-order combine of the 32 slots -> one (count, mean, M2) triple per (group, channel).
+// Stage 2: the same kernel over the stage-1 triples with one group and final = 1.  fp64, deterministic order.
+template <typename T>
+__global__ void __launch_bounds__(1024) moments_from_slabs_kernel(const T* __restrict__ partial, int P, int C,
+                                                                  int final_stage, float eps,
+                                                                  double* __restrict__ group_out,
+                                                                  float* __restrict__ mean, float* __restrict__ stdv) {
+    __shared__ double red[32][32][3];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int slot = threadIdx.x >> 5;
+    const int groups = gridDim.y, grp = blockIdx.y;
+    const int per = (P + groups - 1) / groups;
+    const int k0 = grp * per, k1 = min(P, k0 + per);
+    double n = 0, mu = 0, m2 = 0;
+    for (int k = k0 + slot; k < k1; k += 32) {
+        const T* o = partial + (size_t)k * 3 * C + c;
+        const double bn = (double)o[0], bmu = (double)o[C], bm2 = (double)o[2 * C];
+        if (bn > 0) {
+            const double tot = n + bn, delta = bmu - mu;
+            m2 += bm2 + delta * delta * (n * bn / tot);
+            mu += delta * (bn / tot);
+            n = tot;
+        }
+    }
+    red[slot][threadIdx.x & 31][0] = n; red[slot][threadIdx.x & 31][1] = mu; red[slot][threadIdx.x & 31][2] = m2;
+    __syncthreads();
+    if (slot == 0) {
+        for (int k = 1; k < 32; ++k) {
+            const double bn = red[k][threadIdx.x][0], bmu = red[k][threadIdx.x][1], bm2 = red[k][threadIdx.x][2];
+            if (bn > 0) {
+                const double tot = n + bn, delta = bmu - mu;
+                m2 += bm2 + delta * delta * (n * bn / tot);
+                mu += delta * (bn / tot);
+                n = tot;
+            }
+        }
+        if (final_stage) {
+            const double var = n > 0 ? m2 / n : 0.0;
+            mean[c] = (float)mu;
+            stdv[c] = sqrtf((float)var + eps);
+        } else {
+            double* o = group_out + (size_t)grp * 3 * C + c;
+            o[0] = n; o[C] = mu; o[2 * C] = m2;
+        }
+    }
+}
+
+hipError_t launch_moments_from_slabs(const float* partial, int P, int C, float eps, double* group_ws, float* mean,
+                                     float* stdv, hipStream_t s) {
+    if (C % 32 || P <= 0) return hipErrorInvalidValue;
+    int groups = P / 64;
+    if (groups > 32) groups = 32;
+    if (groups <= 1) {
+        moments_from_slabs_kernel<float><<<dim3(C / 32, 1), 1024, 0, s>>>(partial, P, C, 1, eps, nullptr, mean, stdv);
+    } else {
+        moments_from_slabs_kernel<float><<<dim3(C / 32, groups), 1024, 0, s>>>(partial, P, C, 0, eps, group_ws, mean, stdv);
+        moments_from_slabs_kernel<double><<<dim3(C / 32, 1), 1024, 0, s>>>(group_ws, groups, C, 1, eps, nullptr, mean, stdv);
+    }
+    return hipGetLastError();
 }
 
 int conv_pick_tile(int M, int N, int epilogue, int prec) {

@@ -42,6 +42,8 @@ struct ConvParams {
     float* partial;               // [ksplit][B*Hout*Wout][N] workspace for split-K
     int prec;                     // PREC_F32: operands are fp32; PREC_BF16X3: operands are split-bf16 words
     int out_split;                // EPI_SPADE only: write the split-bf16 image (the consumer conv runs PREC_BF16X3)
+    float* stat_partial;          // EPI_BIAS / EPI_RES, ksplit == 1: per-wave partial moments of the OUTPUT,
+                                  // [P][3][N] = (count, mean, M2) per 32- or 64-row slab (P = conv_stat_slabs)
     int wt_frag;                  // PREC_BF16X3: weights are in MFMA-fragment order (conv_igemm_bf16x3, B in VGPRs)
                                   // instead of the split-bf16 image of [tap][N][Cin] (LDS-staged B)
 };
@@ -82,6 +84,12 @@ hipError_t launch_conv_igemm(const ConvParams& p, int epilogue, int tile, hipStr
 // picks the tile and the K split for a problem size (fills the chip for the low-resolution layers)
 int conv_pick_tile(int M, int N, int epilogue, int prec);
 int conv_pick_ksplit(int M, int N, int ksteps, int tile);
+// number of partial-moment slabs the fused epilogue of this launch writes (0 if the shape is not tileable)
+int conv_stat_slabs(const ConvParams& p, int tile);
+// Chan-combines the slabs in fp64: mean and sqrt(biased var + eps) per channel (deterministic order)
+// group_ws: 32 * 3 * C doubles of scratch
+hipError_t launch_moments_from_slabs(const float* partial, int P, int C, float eps, double* group_ws, float* mean,
+                                     float* stdv, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // Small kernels (memory-bound or tiny)
