@@ -198,7 +198,7 @@ def main():
                 res["roofline"]["frac_of_executed_mfma_peak"] = 3 * ach / peak
             pmc = pmc_traffic(args.workload + ("" if args.precision == "fp32" else "_bf16x3"))
             if pmc and "conv_igemm" in pmc[0]:
-                res["roofline"]["traffic"] = pmc[0]["conv_igemm"]["hbm_bytes_per_launch"]
+                res["roofline"]["traffic"] = pmc[0]["conv_igemm"]["hbm_bytes_per_forward"] / (conv["launches"] / args.steps)
                 res["roofline"]["traffic_source"] = "profiles/" + pmc[1]
             res["kernel_ms_per_call"] = {k: v["device_ms"] / args.steps for k, v in stats.items()}
         if world == 1 and not args.no_cpu_baseline:
