@@ -154,3 +154,32 @@ def test_full_size_stitch_properties(dsr):
     mean2, std2, good2 = d.rebuildTile(pred[: int(keep.sum())], torch.from_numpy(keys[keep]).cuda(), mm[: int(keep.sum())])
     assert good2[100:].all() and torch.all(mean2[good2.bool()] == 50.0)
     d.close()
+
+
+@pytest.mark.parametrize("S,stride,B,T,shape,hole", [
+    (64, 32, 3, 128, (150, 70), None),                 # raster narrower than a tile, batch size that never fills
+    (64, 8, 16, 64, (90, 200), (20, 60, 100, 130)),    # dense overlap (stride S/8), small tiles, nodata block
+    (128, 32, 5, 256, (300, 300), (0, 300, 140, 150)), # S=128, a nodata stripe through the whole raster
+    (64, 64, 4, 128, (130, 130), (10, 20, 10, 20)),    # stride == image_size: no overlap at all
+])
+def test_identity_map_bit_exact_many_geometries(dsr, S, stride, B, T, shape, hole):
+    """Randomised geometry sweep of the whole tiler + stitcher against the NumPy oracle (float32 identity model):
+    padded canvas, tile list, validity, batch composition, normalisation, stitching, assembly — bit for bit."""
+    DEMSuperResolution, DSRConfig = dsr
+    img, dem = synthetic_raster(shape[0], shape[1], seed=S + stride, hole=hole)
+    d = DEMSuperResolution(DSRConfig(image_size=S, stride=stride, batch_size=B, tile_size=T), model=f32_identity)
+    mean, std, good = d.processMap(img, dem)
+    rm, rs, rg = tiler_ref.process_map(img, dem, f32_identity, S, stride, B, T, NOVAL)
+    assert mean.shape == shape and np.array_equal(good, rg)
+    assert np.array_equal(mean, rm) and np.array_equal(std, rs)
+    d.close()
+
+
+def test_all_nodata_raster_gives_no_value_everywhere(dsr):
+    DEMSuperResolution, DSRConfig = dsr
+    img = np.full((100, 100), 0.5, np.float32)
+    dem = np.full((100, 100), NOVAL, np.float32)
+    d = DEMSuperResolution(DSRConfig(image_size=64, stride=32, batch_size=4, tile_size=128), model=f32_identity)
+    mean, std, good = d.processMap(img, dem)
+    assert not good.any() and (mean == NOVAL).all() and (std == NOVAL).all()
+    d.close()
