@@ -125,6 +125,12 @@ int msr_set_blend_window(msr_handle* h, const double* host_window, int32_t side)
  * weight reader (moonsuperresolution_amd/tf_checkpoint.py): checkpoint data and index blocks carry masked CRC-32C. */
 uint32_t msr_crc32c(const void* host_data, uint64_t n, uint32_t crc);
 
+/* TIFF 6.0 LZW (compression 5) of HOST buffers, for the GeoTIFF reader / writer (moonsuperresolution_amd/geotiff.py;
+ * the reference reads and writes LZW GeoTIFFs through GDAL: process_full_tiles.py:158-182, 481-531).
+ * Both return the number of bytes produced, or -1 on a malformed stream / too small output buffer. */
+int64_t msr_lzw_decode(const uint8_t* in, int64_t n_in, uint8_t* out, int64_t n_out);
+int64_t msr_lzw_encode(const uint8_t* in, int64_t n_in, uint8_t* out, int64_t cap);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 typedef struct {
     char name[48];        /* kernel family, e.g. "conv_igemm_f32" */

@@ -47,6 +47,8 @@ SYMBOLS = [
     ("msr_stitch_tile", C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, _P, _P, _P]),
     ("msr_set_blend_window", C.c_int, [_P, _P, C.c_int32]),
     ("msr_crc32c", C.c_uint32, [_P, C.c_uint64, C.c_uint32]),
+    ("msr_lzw_decode", C.c_int64, [_P, C.c_int64, _P, C.c_int64]),
+    ("msr_lzw_encode", C.c_int64, [_P, C.c_int64, _P, C.c_int64]),
     ("msr_profile_enable", C.c_int, [_P, C.c_int32]),
     ("msr_profile_reset", C.c_int, [_P]),
     ("msr_profile_read", C.c_int, [_P, C.POINTER(MsrKernelStat), C.c_int32, C.POINTER(C.c_int32)]),

@@ -1,9 +1,10 @@
 """Tiled inference driver on the GPU — the host-side mirror of ``DEMSuperResolution`` (process_full_tiles.py:129-587).
 
 Same names and argument meaning as the reference for the part of the class that is on the hot path
-(``DSRConfig``, ``padInputs``, ``generateTileList``, ``processTile``, ``rebuildTile``, ``rebuildMap``); raster file
-I/O and nodata in-filling (``loadImages``/``preprocess``/``saveGTiff``: GDAL, OpenCV, SciPy) are out of scope
- — rasters come in as arrays through ``setImages``.
+(``DSRConfig``, ``padInputs``, ``generateTileList``, ``processTile``, ``rebuildTile``, ``rebuildMap``) and for the
+file boundary either side of it (``loadImages`` / ``saveGTiff`` on ``geotiff.py`` instead of GDAL).  Nodata
+in-filling and low-res-DEM synthesis (``preprocess``: OpenCV, SciPy) are not built — feed
+pre-processed rasters, as files (``processFiles``) or as arrays (``setImages`` / ``processMap``).
 
 What moves to the GPU (libmoonsr_hip.so, csrc/tiler.hip):
   getPatch + normalize     -> msr_patch_stats + msr_extract_patches   (validity, min/max, [-0.5,0.5] scaling)
@@ -17,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import dataclasses
+import os
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -76,6 +78,8 @@ class DEMSuperResolution:
         self.map_name = config.map_name
         self.save_path = config.save_path
         self.folder_path = config.source_folder_path
+        self.left_image_name = config.ortho_image_name
+        self.dem_name = config.dem_name
         self.no_value = float(config.no_value)
         self.stride = int(config.stride)
         self.image_size = int(config.image_size)
@@ -123,6 +127,58 @@ class DEMSuperResolution:
         self.img, self.dem = img, dem
         self.dem_shape = dem.shape
         self.img_shape = img.shape
+
+    def loadImages(self) -> None:
+        """process_full_tiles.py:158-182 without GDAL: band 1 of ``<source_folder_path>/<ortho_image_name>`` and
+        ``<dem_name>`` as float32 (geotiff.read_geotiff), georeferencing of the DEM kept for saveGTiff.
+
+        Raises ValueError if a path does not exist (same messages as the reference)."""
+        from . import geotiff
+        img_path = os.path.join(self.folder_path, self.left_image_name)
+        dem_path = os.path.join(self.folder_path, self.dem_name)
+        if not os.path.exists(img_path):
+            raise ValueError("The path given for the ortho-image does not exist. Provided path is: " + img_path)
+        if not os.path.exists(dem_path):
+            raise ValueError("The path given for the dem does not exist. Provided path is: " + dem_path)
+        img, _ = geotiff.read_geotiff(img_path, band=1)
+        dem, self.geo_meta = geotiff.read_geotiff(dem_path, band=1)
+        self.geo_transform = geotiff.geotransform(self.geo_meta)
+        self.setImages(img, dem)
+
+    def saveGTiff(self, data: np.ndarray, data_type, name: str) -> None:
+        """process_full_tiles.py:481-531 without GDAL: ``<save_path>/<map_name>_<name>.tiff``, LZW + PREDICTOR=2,
+        the input DEM's georeferencing, nodata = no_value; uint8 data is stored as UInt16 like the reference does.
+
+        Raises ValueError for unsupported data types and for data that is not 2-dimensional."""
+        from . import geotiff
+        if data_type == np.float32:
+            out_type = np.float32
+        elif data_type == np.uint8 or data_type == np.uint16:
+            out_type = np.uint16
+            data = data.astype(np.uint16)
+        else:
+            raise ValueError("Unsupported data-type.")
+        if len(data.shape) < 2:
+            raise ValueError("Data is of incorrect shape. The array must be 2-dimensional at least.")
+        if len(data.shape) == 3 and data.shape[2] == 1:
+            data = data[:, :, 0]
+        elif len(data.shape) != 2:
+            raise ValueError("Data is of incorrect shape")
+        os.makedirs(self.save_path, exist_ok=True)
+        geotiff.write_geotiff(os.path.join(self.save_path, self.map_name + "_" + name + ".tiff"), data,
+                              getattr(self, "geo_meta", None), nodata=self.no_value, dtype=out_type, compress="lzw",
+                              predictor=2)
+
+    def processFiles(self) -> None:
+        """processMap of the reference on files (process_full_tiles.py:568-587): loadImages -> padInputs -> tiles ->
+        rebuildMap -> ``<map>_mean.tiff``, ``<map>_std.tiff``, ``<map>_good.tiff``.  The reference's ``preprocess``
+        (nodata in-filling and low-res-DEM synthesis with OpenCV / SciPy) is not part of this build: the DEM is used
+        as read, so feed the already pre-processed low-resolution DEM."""
+        self.loadImages()
+        mean, std, good = self.processMap()
+        self.saveGTiff(mean, mean.dtype, "mean")
+        self.saveGTiff(std, std.dtype, "std")
+        self.saveGTiff(good, good.dtype, "good")
 
     def padInputs(self) -> None:
         """process_full_tiles.py:246-267: no_value canvas ((dim//1024)+1)*1024 + 2(S-s), data at offset (S-s)."""

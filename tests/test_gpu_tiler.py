@@ -183,3 +183,39 @@ def test_all_nodata_raster_gives_no_value_everywhere(dsr):
     mean, std, good = d.processMap(img, dem)
     assert not good.any() and (mean == NOVAL).all() and (std == NOVAL).all()
     d.close()
+
+
+def test_files_in_files_out(dsr, tmp_path):
+    """loadImages -> tiles -> rebuildMap -> saveGTiff on real files (process_full_tiles.py:568-587 without GDAL):
+    the three products are LZW/predictor-2 GeoTIFFs carrying the input DEM's georeferencing and nodata, readable
+    by libtiff, and hold exactly what the in-memory path computes."""
+    import struct
+    from PIL import Image
+    from moonsuperresolution_amd import geotiff
+    DEMSuperResolution, DSRConfig = dsr
+    img, dem = synthetic_raster(180, 260, 12, hole=(60, 90, 100, 150))
+    meta = {"geo": {33550: (12, 3, struct.pack("<3d", 5.0, 5.0, 0.0)),
+                    33922: (12, 6, struct.pack("<6d", 0, 0, 0, 7000.0, 900.0, 0))}, "byteorder": "<"}
+    src = tmp_path / "src"
+    src.mkdir()
+    geotiff.write_geotiff(str(src / "run-DRG.tif"), img, meta, nodata=NOVAL)
+    geotiff.write_geotiff(str(src / "run-DEM.tif"), dem, meta, nodata=NOVAL)
+    cfg = DSRConfig(image_size=64, stride=16, batch_size=4, tile_size=128, map_name="apollo", save_path=str(tmp_path / "out"),
+                    source_folder_path=str(src))
+    d = DEMSuperResolution(cfg, model=f32_identity)
+    d.processFiles()
+    rm, rs, rg = tiler_ref.process_map(img, dem, f32_identity, 64, 16, 4, 128, NOVAL)
+    for name, ref in (("mean", rm), ("std", rs), ("good", rg)):
+        arr, m = geotiff.read_geotiff(str(tmp_path / "out" / f"apollo_{name}.tiff"))
+        assert np.array_equal(arr, ref.astype(np.float32)) and m["nodata"] == NOVAL
+        assert geotiff.geotransform(m) == (7000.0, 5.0, 0.0, 900.0, 0.0, -5.0)
+        assert m["dtype"] == (np.uint16 if name == "good" else np.float32)          # good is stored as UInt16 (:499-501)
+        with Image.open(str(tmp_path / "out" / f"apollo_{name}.tiff")) as im:
+            assert np.array_equal(np.array(im).astype(np.float32), arr)
+    with pytest.raises(ValueError):
+        d.saveGTiff(np.zeros((4, 4), np.float64), np.float64, "bad")
+    bad = DEMSuperResolution(DSRConfig(image_size=64, stride=16, batch_size=4, tile_size=128, map_name="m",
+                                       save_path=str(tmp_path), source_folder_path=str(tmp_path / "nowhere")), model=f32_identity)
+    with pytest.raises(ValueError):
+        bad.loadImages()
+    d.close(); bad.close()
