@@ -91,8 +91,8 @@ def cpu_baseline(S: int, sample_patches: int, weights, eps_full):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="spade256")
     ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="bf16x3",
                     help="conv arithmetic: exact fp32 MFMA, or 3-term split-bf16 on the bf16 MFMA (fp32 accumulate)")
