@@ -56,7 +56,8 @@ typedef struct {
 /* Conv arithmetic.  Default (0): exact fp32 on v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak).
  * MSR_FLAG_BF16X3: 3-term split-bf16 products (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi) on v_mfma_f32_32x32x16_bf16
  * with fp32 accumulation: per-product error <= ~3*2^-18, all other arithmetic (moments, normalisation, epilogues,
- * dense, head) stays fp32.  Inputs, outputs and weights of the C ABI are fp32 either way. */
+ * dense, head) stays fp32.  Inputs, outputs and weights of the C ABI are fp32 either way.  MSR_PIX2PIX ignores the
+ * flag and always computes on the fp32 MFMA. */
 #define MSR_FLAG_BF16X3 1
 
 typedef struct msr_handle msr_handle;

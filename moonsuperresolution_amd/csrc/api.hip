@@ -46,7 +46,7 @@ struct Op {
     NormActParams na{};
     struct { const float* x; const float* W; const float* bias; float* y; int B, K, N; } dense{};
     struct { const float* mv; float* z; int B, L, sampler; } lat{};
-    struct { const float* x; const float* weff; float bias; int B, r, C; float slope; int tanh_out; } head{};
+    struct { const float* x; const float* weff; float bias; int B, r, C; float slope; int tanh_out; int x_py, x_pb; } head{};
     DirectConvParams dc{};
 };
 
@@ -359,6 +359,7 @@ int msr_create(const msr_config* cfg, msr_handle** out) {
     h->cfg = *cfg;
     h->S = S; h->B = B; h->L = cfg->latent_dim; h->variant = cfg->variant;
     h->prec = (cfg->flags & MSR_FLAG_BF16X3) ? PREC_BF16X3 : PREC_F32;
+    if (cfg->variant == MSR_PIX2PIX) h->prec = PREC_F32;   // the 11.9-GFLOP parity config runs on the fp32 MFMA
     build_specs(h.get());
     *out = h.release();
     return MSR_OK;
@@ -427,16 +428,42 @@ int msr_load_weight(msr_handle* h, const char* name_c, const float* host, const 
     int rc = MSR_OK;
     const auto& s = sp.shape;
     if (name.rfind("p2p.", 0) == 0) {
-        if (ends_with(name, ".kernel") && name.find(".down") == std::string::npos) {
-            // Conv2DTranspose [kh,kw,Cout,Cin] -> HWIO [kh,kw,Cin,Cout]
-            const int taps = 16, co = (int)s[2], ci = (int)s[3];
-            std::vector<float> t(count);
-            for (int tp = 0; tp < taps; ++tp)
-                for (int o = 0; o < co; ++o)
-                    for (int i = 0; i < ci; ++i) t[((size_t)tp * ci + i) * co + o] = host[((size_t)tp * co + o) * ci + i];
-            rc = upload(h, name, t.data(), count);
+        // Conv2DTranspose(k=4, s=2, 'same') is four stride-1 2x2 convolutions, one per output parity (py, px):
+        // out[2y+py][2x+px] = sum_{t,u} in[y-1+py+t][x-1+px+u] * W[kmap(py,t)][kmap(px,u)], kmap(0,.) = {3,1},
+        // kmap(1,.) = {2,0}  (from kh = o + 1 - 2i, the transpose of the 'same' stride-2 forward conv).
+        static const int kmap[2][2] = {{3, 1}, {2, 0}};
+        if (name == "p2p.down1.kernel") {
+            rc = upload(h, name, host, count);                       // conv_direct reads HWIO
+        } else if (name == "p2p.last.kernel") {
+            // [4,4,1,C] -> the head kernel's effective taps weff[py][px][dy][dx][C], offset dy-1 = py+t-1
+            const int C = (int)s[3];
+            std::vector<float> weff((size_t)36 * C, 0.f);
+            for (int py = 0; py < 2; ++py)
+                for (int px = 0; px < 2; ++px)
+                    for (int t = 0; t < 2; ++t)
+                        for (int u = 0; u < 2; ++u) {
+                            const float* src = host + ((size_t)kmap[py][t] * 4 + kmap[px][u]) * C;
+                            float* dst = &weff[((((size_t)py * 2 + px) * 3 + (py + t)) * 3 + (px + u)) * C];
+                            std::copy(src, src + C, dst);
+                        }
+            rc = upload(h, "p2p.last.weff", weff.data(), weff.size());
+        } else if (ends_with(name, ".kernel") && name.find(".down") == std::string::npos) {
+            // [kh,kw,Cout,Cin] is already K-contiguous per output channel: four parity images [2x2 taps][Cout][Cin]
+            const size_t co = (size_t)s[2], ci = (size_t)s[3];
+            std::vector<float> t4(count);
+            for (int py = 0; py < 2; ++py)
+                for (int px = 0; px < 2; ++px)
+                    for (int t = 0; t < 2; ++t)
+                        for (int u = 0; u < 2; ++u) {
+                            const float* src = host + ((size_t)kmap[py][t] * 4 + kmap[px][u]) * co * ci;
+                            std::copy(src, src + co * ci, t4.data() + ((size_t)(py * 2 + px) * 4 + t * 2 + u) * co * ci);
+                        }
+            rc = upload(h, name, t4.data(), count);
         } else if (ends_with(name, ".kernel")) {
-            rc = upload(h, name, host, count);
+            // down2..8: HWIO -> [tap][Cout][Cin]
+            std::vector<float> t(count);
+            hwio_to_tap_oc_ic(host, t.data(), 16, (int)s[2], (int)s[3], (int)s[3], nullptr);
+            rc = upload(h, name, t.data(), count);
         } else {
             h->host_small[name].assign(host, host + count);   // BN statistics / bias: folded at plan time
         }
@@ -556,7 +583,7 @@ Op conv_op(const Padded& in, const float* wt, const float* bias, int B, int rout
     c.wt = wt; c.bias = bias;
     c.B = B; c.Hout = rout; c.Wout = rout; c.Cin = in.C; c.N = N;
     c.KH = 3; c.KW = 3; c.stride = stride;
-    c.in_py = in.py(); c.in_pb = in.pb();
+    c.in_px = in.C; c.in_py = in.py(); c.in_pb = in.pb();
     c.slope = 0.2f;
     c.prec = prec;
     c.out_split = (epi == EPI_SPADE && prec == PREC_BF16X3) ? 1 : 0;   // a SPADE output always feeds a conv
@@ -758,7 +785,7 @@ int plan_spade(msr_handle* h) {
     }
     {
         Op hd; hd.type = OP_HEAD; hd.out_is_output = true;
-        hd.head = {x_prev, need("gen.head.weff"), h->host_small["gen.head.bias"][0], B, r_prev, 128, 0.2f, 0};
+        hd.head = {x_prev, need("gen.head.weff"), h->host_small["gen.head.bias"][0], B, r_prev, 128, 0.2f, 0, 0, 0};
         hd.flops = 2.0 * B * S * S * 16.0 * 128;
         h->ops.push_back(hd);
     }
@@ -788,67 +815,91 @@ int plan_pix2pix(msr_handle* h) {
         *scale = D(h, prefix + ".scale"); *shift = D(h, prefix + ".shift");
         return MSR_OK;
     };
-    float* down[9] = {nullptr};
-    int cin = 2, r = 256;
-    for (int i = 1; i <= 8; ++i) {
-        const int c = kP2PDown[i - 1];
-        snprintf(n, sizeof n, "ws.p2p.down%d", i);
-        rc = dev_alloc(h, n, (size_t)B * (r / 2) * (r / 2) * c, false, &down[i]); if (rc) return rc;
-        Op op; op.type = OP_DIRECT; op.src_is_input = (i == 1);
+    // Activations live in zero-bordered concat buffers cat_i = [up_i | down_(8-i)] (pix2pix.py:99-104 concatenates
+    // [x, skip]): a down block writes its half once, the next down block reads it as a channel slice
+    // (in_px = total channels) and the up path reads the whole pixel.  No concat copy exists.
+    Padded cat[8];           // cat[i], i = 1..7, at resolution 2^i
+    Padded d8;               // the 1x1 bottleneck
+    for (int i = 1; i <= 7; ++i) {
+        const int cu = kP2PUp[i - 1], cd = kP2PDown[6 - (i - 1)];
+        snprintf(n, sizeof n, "ws.p2p.cat%d", i);
+        rc = alloc_padded(h, n, 1 << i, cu + cd, &cat[i]); if (rc) return rc;
+    }
+    rc = alloc_padded(h, "ws.p2p.down8", 1, 512, &d8); if (rc) return rc;
+    auto igemm = [&](const float* in, int in_px, int in_py, int in_pb, int cin, const float* wt, const float* scale,
+                     const float* shift, int rout, int N, int K, int stride, int act, float slope) {
+        Op op; op.type = OP_CONV; op.epi = EPI_AFFINE;
+        ConvParams& c = op.conv;
+        c.in = in; c.wt = wt; c.bias = shift; c.scale = scale; c.act = act; c.slope = slope;
+        c.B = B; c.Hout = rout; c.Wout = rout; c.Cin = cin; c.N = N; c.KH = K; c.KW = K; c.stride = stride;
+        c.in_px = in_px; c.in_py = in_py; c.in_pb = in_pb;
+        c.prec = PREC_F32;
+        op.tile = conv_pick_tile(B * rout * rout, N, EPI_AFFINE, PREC_F32);
+        c.ksplit = conv_pick_ksplit(B * rout * rout, N, K * K * (cin / 32), op.tile);
+        op.flops = 2.0 * B * rout * rout * (double)cin * N * K * K;
+        return op;
+    };
+    // ---- down1: 2 -> 64 channels, no BatchNormalization (pix2pix.py:27), on the direct kernel ----
+    {
+        const Padded& o = cat[7];
+        Op op; op.type = OP_DIRECT; op.src_is_input = true;
         DirectConvParams& p = op.dc;
-        p.in0 = i == 1 ? nullptr : down[i - 1]; p.c0 = cin; p.in1 = nullptr; p.c1 = 0;
-        snprintf(n, sizeof n, "p2p.down%d.kernel", i); p.w = D(h, n);
-        p.scale = p.shift = nullptr;
-        if (i > 1) {
-            snprintf(n, sizeof n, "p2p.down%d.bn", i);
-            float *sc, *sh; rc = fold_bn(n, c, &sc, &sh); if (rc) return rc;
-            p.scale = sc; p.shift = sh;
-        }
-        p.out = down[i]; p.out_c = c; p.out_coff = 0;
-        p.B = B; p.Hin = r; p.Win = r; p.Hout = r / 2; p.Wout = r / 2; p.Cout = c;
+        p.in0 = nullptr; p.c0 = 2; p.in1 = nullptr; p.c1 = 0;
+        p.in_px = 2; p.in_py = 256 * 2; p.in_pb = 256 * 256 * 2;
+        p.w = D(h, "p2p.down1.kernel"); p.scale = p.shift = nullptr;
+        p.out = o.base + o.interior() + kP2PUp[6]; p.out_px = o.C; p.out_py = o.py(); p.out_pb = o.pb();
+        p.B = B; p.Hin = 256; p.Win = 256; p.Hout = 128; p.Wout = 128; p.Cout = 64;
         p.KH = 4; p.KW = 4; p.stride = 2; p.pad = 1; p.transposed = 0;
         p.act = 2; p.slope = 0.3f;   // keras LeakyReLU() default alpha (pix2pix.py:72)
-        op.flops = 2.0 * B * (r / 2) * (r / 2) * 16.0 * cin * c;
+        op.flops = 2.0 * B * 128 * 128 * 16.0 * 2 * 64;
         h->ops.push_back(op);
-        cin = c; r /= 2;
     }
-    float* x = down[8];
-    int c0 = 512, c1 = 0;
-    float* skip = nullptr;
+    // ---- down2..8: 4x4 stride-2 implicit GEMM; the padded border is the 'same' padding (1 before, 1 after) ----
+    for (int i = 2; i <= 8; ++i) {
+        const int cin = kP2PDown[i - 2], c = kP2PDown[i - 1];
+        const Padded& src = cat[8 - (i - 1)];
+        const int src_off = kP2PUp[8 - (i - 1) - 1];          // the skip half starts after the up half
+        const int rout = 256 >> i;
+        snprintf(n, sizeof n, "p2p.down%d.bn", i);
+        float *sc, *sh; rc = fold_bn(n, c, &sc, &sh); if (rc) return rc;
+        snprintf(n, sizeof n, "p2p.down%d.kernel", i);
+        Op op = igemm(src.base + src_off, src.C, src.py(), src.pb(), cin, D(h, n), sc, sh, rout, c, 4, 2, 2, 0.3f);
+        if (i < 8) {
+            const Padded& o = cat[8 - i];
+            set_out_padded(op.conv, o);
+            op.conv.out_off += kP2PUp[8 - i - 1];
+        } else {
+            set_out_padded(op.conv, d8);
+        }
+        h->ops.push_back(op);
+    }
+    // ---- up1..7: Conv2DTranspose + BatchNormalization (+ Dropout, identity at inference) + ReLU
+    //      (pix2pix.py:76-94) as four parity sub-convolutions writing interleaved pixels of cat_i's up half ----
     for (int i = 1; i <= 7; ++i) {
-        const int c = kP2PUp[i - 1];
-        float* up;
-        snprintf(n, sizeof n, "ws.p2p.up%d", i);
-        rc = dev_alloc(h, n, (size_t)B * (2 * r) * (2 * r) * c, false, &up); if (rc) return rc;
-        Op op; op.type = OP_DIRECT;
-        DirectConvParams& p = op.dc;
-        p.in0 = x; p.c0 = c0; p.in1 = skip; p.c1 = c1;
-        snprintf(n, sizeof n, "p2p.up%d.kernel", i); p.w = D(h, n);
+        const Padded& src = i == 1 ? d8 : cat[i - 1];
+        const Padded& o = cat[i];
+        const int c = kP2PUp[i - 1], r = src.r;
         snprintf(n, sizeof n, "p2p.up%d.bn", i);
         float *sc, *sh; rc = fold_bn(n, c, &sc, &sh); if (rc) return rc;
-        p.scale = sc; p.shift = sh;
-        p.out = up; p.out_c = c; p.out_coff = 0;
-        p.B = B; p.Hin = r; p.Win = r; p.Hout = 2 * r; p.Wout = 2 * r; p.Cout = c;
-        p.KH = 4; p.KW = 4; p.stride = 2; p.pad = 1; p.transposed = 1;
-        p.act = 1; p.slope = 0.f;
-        op.flops = 2.0 * B * r * r * 16.0 * (c0 + c1) * c;
-        h->ops.push_back(op);
-        x = up; c0 = c; skip = down[7 - (i - 1)]; c1 = kP2PDown[6 - (i - 1)];
-        r *= 2;
+        snprintf(n, sizeof n, "p2p.up%d.kernel", i);
+        const float* w = D(h, n);
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+                Op op = igemm(src.base + py * src.py() + px * src.C, src.C, src.py(), src.pb(), src.C,
+                              w + (size_t)(py * 2 + px) * 4 * c * src.C, sc, sh, r, c, 2, 1, 1, 0.f);
+                ConvParams& cp = op.conv;
+                cp.out = o.base; cp.out_px = 2 * o.C; cp.out_py = 2 * o.py(); cp.out_pb = o.pb();
+                cp.out_off = o.interior() + py * o.py() + px * o.C;
+                h->ops.push_back(op);
+            }
     }
+    // ---- last: Conv2DTranspose(1, 4, 2, 'same', tanh) (pix2pix.py:53-57) = per-parity 2x2 taps on the head kernel ----
     {
-        Op op; op.type = OP_DIRECT; op.out_is_output = true;
-        DirectConvParams& p = op.dc;
-        p.in0 = x; p.c0 = c0; p.in1 = skip; p.c1 = c1;
-        p.w = D(h, "p2p.last.kernel");
-        p.scale = nullptr;
-        rc = upload(h, "p2p.last.shift", h->host_small["p2p.last.bias"].data(), 1); if (rc) return rc;
-        p.shift = D(h, "p2p.last.shift");
-        p.out = nullptr; p.out_c = 1; p.out_coff = 0;
-        p.B = B; p.Hin = r; p.Win = r; p.Hout = 2 * r; p.Wout = 2 * r; p.Cout = 1;
-        p.KH = 4; p.KW = 4; p.stride = 2; p.pad = 1; p.transposed = 1;
-        p.act = 3; p.slope = 0.f;
-        op.flops = 2.0 * B * r * r * 16.0 * (c0 + c1) * 1;
+        const Padded& src = cat[7];
+        Op op; op.type = OP_HEAD;
+        op.head = {src.base + src.interior(), D(h, "p2p.last.weff"), h->host_small["p2p.last.bias"][0], B, 128, src.C,
+                   1.0f, 1, src.py(), src.pb()};
+        op.flops = 2.0 * B * 128 * 128 * 16.0 * src.C;
         h->ops.push_back(op);
     }
     return MSR_OK;
@@ -992,7 +1043,7 @@ int msr_forward(msr_handle* h, const float* in_dev, const float* eps_dev, float*
             case OP_HEAD:
                 fam = FAM_HEAD;
                 e = launch_head(op.head.x, op.head.weff, op.head.bias, out_dev, op.head.B, op.head.r, op.head.C,
-                                op.head.slope, op.head.tanh_out, s);
+                                op.head.slope, op.head.tanh_out, op.head.x_py, op.head.x_pb, s);
                 break;
             case OP_DIRECT: {
                 fam = FAM_DIRECT;

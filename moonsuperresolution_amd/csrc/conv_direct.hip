@@ -2,21 +2,25 @@
 // (pix2pix.py:65-108) — BASELINE config 1, the "plumbing / parity" configuration (11.9 GFLOP per patch).
 // Lanes run along output channels (coalesced HWIO weight rows, wave-uniform input reads); the folded
 // BatchNormalization affine, the skip-connection concat (two input pointers) and the activation are fused.
+// It serves down1 (2 input channels: no K to tile); every other pix2pix layer runs on conv_igemm (4x4 s2 convs,
+// transposed convs as four parity 2x2 convs) and the 1-channel tanh output on the head kernel.
 #include "kernels.h"
 
 namespace msr {
 
+// One thread = 4 consecutive output channels of one pixel (float4 weight rows, float4 store); Cout % 4 == 0.
 __global__ void __launch_bounds__(256) conv_direct_kernel(const DirectConvParams p) {
     const int cin = p.c0 + p.c1;
-    const long total = (long)p.B * p.Hout * p.Wout * p.Cout;
+    const int cq = p.Cout >> 2;
+    const long total = (long)p.B * p.Hout * p.Wout * cq;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int co = (int)(i % p.Cout);
-        long pix = i / p.Cout;
+        const int co = (int)(i % cq) * 4;
+        long pix = i / cq;
         const int x = (int)(pix % p.Wout);
         pix /= p.Wout;
         const int y = (int)(pix % p.Hout);
         const int b = (int)(pix / p.Hout);
-        float acc = 0.f;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int kh = 0; kh < p.KH; ++kh) {
             int iy;
             if (p.transposed) {
@@ -38,26 +42,40 @@ __global__ void __launch_bounds__(256) conv_direct_kernel(const DirectConvParams
                 }
                 if (ix < 0 || ix >= p.Win) continue;
                 const float* w = p.w + ((size_t)(kh * p.KW + kw) * cin) * p.Cout + co;
-                const float* a0 = p.in0 + (((size_t)b * p.Hin + iy) * p.Win + ix) * p.c0;
-                for (int ci = 0; ci < p.c0; ++ci) acc += a0[ci] * w[(size_t)ci * p.Cout];
+                const float* a0 = p.in0 + (size_t)b * p.in_pb + (size_t)iy * p.in_py + (size_t)ix * p.in_px;
+                for (int ci = 0; ci < p.c0; ++ci) {
+                    const float a = a0[ci];
+                    const float4 wv = *reinterpret_cast<const float4*>(w + (size_t)ci * p.Cout);
+                    acc.x += a * wv.x; acc.y += a * wv.y; acc.z += a * wv.z; acc.w += a * wv.w;
+                }
                 if (p.c1) {
-                    const float* a1 = p.in1 + (((size_t)b * p.Hin + iy) * p.Win + ix) * p.c1;
+                    const float* a1 = p.in1 + (size_t)b * p.in_pb + (size_t)iy * p.in_py + (size_t)ix * p.in_px;
                     const float* w1 = w + (size_t)p.c0 * p.Cout;
-                    for (int ci = 0; ci < p.c1; ++ci) acc += a1[ci] * w1[(size_t)ci * p.Cout];
+                    for (int ci = 0; ci < p.c1; ++ci) {
+                        const float a = a1[ci];
+                        const float4 wv = *reinterpret_cast<const float4*>(w1 + (size_t)ci * p.Cout);
+                        acc.x += a * wv.x; acc.y += a * wv.y; acc.z += a * wv.z; acc.w += a * wv.w;
+                    }
                 }
             }
         }
-        if (p.scale) acc *= p.scale[co];
-        if (p.shift) acc += p.shift[co];
-        if (p.act == 1) acc = fmaxf(acc, 0.f);
-        else if (p.act == 2) acc = acc >= 0.f ? acc : acc * p.slope;
-        else if (p.act == 3) acc = tanhf(acc);
-        p.out[(((size_t)b * p.Hout + y) * p.Wout + x) * p.out_c + p.out_coff + co] = acc;
+        float v[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (p.scale) v[k] *= p.scale[co + k];
+            if (p.shift) v[k] += p.shift[co + k];
+            if (p.act == 1) v[k] = fmaxf(v[k], 0.f);
+            else if (p.act == 2) v[k] = v[k] >= 0.f ? v[k] : v[k] * p.slope;
+            else if (p.act == 3) v[k] = tanhf(v[k]);
+        }
+        *reinterpret_cast<float4*>(p.out + (size_t)b * p.out_pb + (size_t)y * p.out_py + (size_t)x * p.out_px + co) =
+            make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
 hipError_t launch_conv_direct(const DirectConvParams& p, hipStream_t s) {
-    const long total = (long)p.B * p.Hout * p.Wout * p.Cout;
+    if (p.Cout % 4 || p.out_px % 4 || p.out_py % 4 || p.out_pb % 4) return hipErrorInvalidValue;
+    const long total = (long)p.B * p.Hout * p.Wout * (p.Cout / 4);
     long blocks = (total + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     conv_direct_kernel<<<(int)blocks, 256, 0, s>>>(p);

@@ -81,6 +81,7 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, const Ti
             ccol[j] = n0 + (wn * NT + j) * 32 + l31;
             cb0[j] = p.bias[ccol[j]];
             cb1[j] = cmean[j] = cstd[j] = 0.f;
+            if constexpr (EPI == EPI_AFFINE) cb1[j] = p.scale ? p.scale[ccol[j]] : 1.f;
         }
     }
     // fused output moments (EPI_BIAS / EPI_RES): shifted sums per lane and column, shift = the lane's first value
@@ -141,6 +142,10 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, const Ti
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     float v = acc[m][n][r] + cb0[n];
+                    if constexpr (EPI == EPI_AFFINE) {
+                        v = acc[m][n][r] * cb1[n] + cb0[n];
+                        v = p.act == 1 ? fmaxf(v, 0.f) : (p.act == 2 ? (v >= 0.f ? v : v * p.slope) : v);
+                    }
                     if constexpr (EPI == EPI_RES) v += xin[q][n];
                     if (ok[q]) orow[ccol[n]] = v;
                     if (mr == 0 && q == 0) st_v0[n] = v;
@@ -255,7 +260,7 @@ conv_igemm(const ConvParams p, const TileGeom g) {
         const int tx = row & twm, ty = (row >> g.tw_l) & thm, tbi = row >> (g.tw_l + g.th_l);
         int b = b0 + tbi;
         b = b < p.B ? b : p.B - 1;   // rows past the batch read valid memory and are dropped in the epilogue
-        a_goff[q] = b * p.in_pb + (ty0 + ty) * p.stride * p.in_py + (tx0 + tx) * p.stride * p.Cin + seg * 4;
+        a_goff[q] = b * p.in_pb + (ty0 + ty) * p.stride * p.in_py + (tx0 + tx) * p.stride * p.in_px + seg * 4;
         a_loff[q] = row * BKP + seg * 4;
     }
     int b_goff[B_ITEMS];
@@ -298,12 +303,12 @@ conv_igemm(const ConvParams p, const TileGeom g) {
     if constexpr (BKC == 32) {
         const int cc0 = t_begin / taps, tap0 = t_begin - cc0 * taps;
         it_cc = cc0; it_kh = tap0 / p.KW; it_kw = tap0 - it_kh * p.KW;
-        a_src = p.in + (it_kh * p.in_py + it_kw * p.Cin + cc0 * BKC);
+        a_src = p.in + (it_kh * p.in_py + it_kw * p.in_px + cc0 * BKC);
         b_src = p.wt + ((size_t)tap0 * w_tap_stride + cc0 * BKC);
     } else {
         const int tap0 = t_begin / chunks, cc0 = t_begin - tap0 * chunks;
         it_cc = cc0; it_kh = tap0 / p.KW; it_kw = tap0 - it_kh * p.KW;
-        a_src = p.in + (it_kh * p.in_py + it_kw * p.Cin + cc0 * BKC);
+        a_src = p.in + (it_kh * p.in_py + it_kw * p.in_px + cc0 * BKC);
         b_src = p.wt + ((size_t)tap0 * w_tap_stride + cc0 * BKC);
     }
 
@@ -329,12 +334,12 @@ conv_igemm(const ConvParams p, const TileGeom g) {
     {                                                                                            \
         if constexpr (BKC == 32) {                                                               \
             ++it_kw;                                                                             \
-            a_src += p.Cin;                                                                      \
+            a_src += p.in_px;                                                                    \
             b_src += w_tap_stride;                                                               \
             if (it_kw == p.KW) {                                                                 \
                 it_kw = 0;                                                                       \
                 ++it_kh;                                                                         \
-                a_src += p.in_py - p.KW * p.Cin;                                                 \
+                a_src += p.in_py - p.KW * p.in_px;                                               \
                 if (it_kh == p.KH) {                                                             \
                     it_kh = 0;                                                                   \
                     a_src += BKC - p.KH * p.in_py;                                               \
@@ -348,12 +353,12 @@ conv_igemm(const ConvParams p, const TileGeom g) {
             if (it_cc == chunks) {                                                               \
                 it_cc = 0;                                                                       \
                 ++it_kw;                                                                         \
-                a_src += p.Cin - chunks * BKC;                                                   \
+                a_src += p.in_px - chunks * BKC;                                                 \
                 b_src += w_tap_stride - chunks * BKC;                                            \
                 if (it_kw == p.KW) {                                                             \
                     it_kw = 0;                                                                   \
                     ++it_kh;                                                                     \
-                    a_src += p.in_py - p.KW * p.Cin;                                             \
+                    a_src += p.in_py - p.KW * p.in_px;                                           \
                 }                                                                                \
             }                                                                                    \
         }                                                                                        \
@@ -873,6 +878,17 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(const ConvParams p
         }
         const float4 b0v = *reinterpret_cast<const float4*>(p.bias + col);
         float4 v = make_float4(a.x + b0v.x, a.y + b0v.y, a.z + b0v.z, a.w + b0v.w);
+        if constexpr (EPI == EPI_AFFINE) {
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + col);
+            v = make_float4(a.x * sc.x + b0v.x, a.y * sc.y + b0v.y, a.z * sc.z + b0v.z, a.w * sc.w + b0v.w);
+            if (p.act == 1) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            } else if (p.act == 2) {
+                v.x = v.x >= 0.f ? v.x : v.x * p.slope; v.y = v.y >= 0.f ? v.y : v.y * p.slope;
+                v.z = v.z >= 0.f ? v.z : v.z * p.slope; v.w = v.w >= 0.f ? v.w : v.w * p.slope;
+            }
+        }
         if constexpr (EPI == EPI_RES || EPI == EPI_SPADE) {
             const float4 xv = *reinterpret_cast<const float4*>(p.aux + (size_t)b * p.aux_pb +
                                                                (size_t)(y >> p.aux_shift) * p.aux_py +
@@ -919,6 +935,7 @@ static hipError_t set_attr_all() {
     if ((e = set_attr<WM, WN, MT, NT, BKC, EPI_BIAS, PREC>()) != hipSuccess) return e;
     if ((e = set_attr<WM, WN, MT, NT, BKC, EPI_RES, PREC>()) != hipSuccess) return e;
     if ((e = set_attr<WM, WN, MT, NT, BKC, EPI_SPADE, PREC>()) != hipSuccess) return e;
+    if ((e = set_attr<WM, WN, MT, NT, BKC, EPI_AFFINE, PREC>()) != hipSuccess) return e;
     return set_attr<WM, WN, MT, NT, BKC, EPI_PARTIAL, PREC>();
 }
 
@@ -1097,11 +1114,15 @@ static hipError_t launch_cfg(const ConvParams& p, int epi, hipStream_t s) {
         if (eb > 4096) eb = 4096;
         if (epi == EPI_BIAS) splitk_epilogue_kernel<EPI_BIAS><<<(int)eb, 256, 0, s>>>(p);
         else if (epi == EPI_RES) splitk_epilogue_kernel<EPI_RES><<<(int)eb, 256, 0, s>>>(p);
+        else if (epi == EPI_AFFINE) splitk_epilogue_kernel<EPI_AFFINE><<<(int)eb, 256, 0, s>>>(p);
         else splitk_epilogue_kernel<EPI_SPADE><<<(int)eb, 256, 0, s>>>(p);
         return hipGetLastError();
     }
     const int grid = g.tiles_mn;
     switch (epi) {
+        case EPI_AFFINE:
+            conv_igemm<WM, WN, MT, NT, BKC, EPI_AFFINE, PREC><<<grid, C::NTHR, C::LDS, s>>>(p, g);
+            break;
         case EPI_BIAS:
             conv_igemm<WM, WN, MT, NT, BKC, EPI_BIAS, PREC><<<grid, C::NTHR, C::LDS, s>>>(p, g);
             break;

@@ -20,6 +20,8 @@ enum ConvEpilogue : int {
     EPI_SPADE = 2,  // N = 2C, columns interleaved (gamma block of 32 | beta block of 32):
                     // out = leaky_relu((g+bg) * ((x-mean)/std) + (b+bb))   spade.py:21-24 + blocks.py:30-34
     EPI_PARTIAL = 3,  // split-K: raw accumulators to partial[ks][B,Hout,Wout,N]; splitk_epilogue finishes
+    EPI_AFFINE = 4,   // out = act(acc * scale[c] + shift[c]): folded BatchNormalization + LeakyReLU / ReLU of the
+                      // pix2pix blocks (pix2pix.py:65-86); scale == nullptr means 1
 };
 
 struct ConvParams {
@@ -32,12 +34,15 @@ struct ConvParams {
     const float* stdv;    // EPI_SPADE: [C]  sqrt(var + eps)
     int B, Hout, Wout, Cin, N;
     int KH, KW, stride;
-    int in_py, in_pb;             // input pitches in floats (pixel pitch = Cin)
+    int in_px, in_py, in_pb;      // input pitches in floats (in_px = Cin unless the input is a channel slice of a
+                                  // wider tensor, e.g. the skip half of a pix2pix concat buffer; generic kernel only)
     int out_px, out_py, out_pb;   // output pitches in floats
     int out_off;                  // offset of output pixel (0,0) channel 0 of sample 0
     int aux_px, aux_py, aux_pb;   // aux pitches
     int aux_shift;                // 1 = aux is at half resolution (nearest 2x up-sample folded in)
-    float slope;                  // leaky-relu slope of EPI_SPADE
+    const float* scale;           // EPI_AFFINE: per-channel scale (nullable); the shift is `bias`
+    int act;                      // EPI_AFFINE: 0 none, 1 relu, 2 leaky(slope)
+    float slope;                  // leaky-relu slope of EPI_SPADE / EPI_AFFINE
     int ksplit;                   // > 1: the K loop is cut into ksplit ranges, one workgroup each (low-res layers)
     float* partial;               // [ksplit][B*Hout*Wout][N] workspace for split-K
     int prec;                     // PREC_F32: operands are fp32; PREC_BF16X3: operands are split-bf16 words
@@ -145,19 +150,21 @@ hipError_t launch_latent(const float* mv, const float* eps, float* z, int B, int
 
 // Head: leaky_relu -> UpSampling2D(2) -> Conv2D(1, 4, 'same') (+tanh) fused (networks.py:54-56).
 //   x [B, r, r, C] at half resolution, weff = [2][2][3][3][C] effective per-parity weights, out [B, 2r, 2r].
-hipError_t launch_head(const float* x, const float* weff, float bias, float* out, int B, int r, int C,
-                       float slope, int tanh_out, hipStream_t s);
+hipError_t launch_head(const float* x, const float* weff, float bias, float* out, int B, int r, int C, float slope,
+                       int tanh_out, int x_py, int x_pb, hipStream_t s);   // x_py = 0: dense [B,r,r,C]
 
 // ---------------------------------------------------------------------------------------------
 // Generic direct convolution (pix2pix plumbing config: Conv2D / Conv2DTranspose 4x4 s2, BN, act, concat)
 // ---------------------------------------------------------------------------------------------
 struct DirectConvParams {
-    const float* in0; int c0;     // first input [B,Hin,Win,c0]
-    const float* in1; int c1;     // optional second input (channel concat), c1 = 0 if none
+    const float* in0; int c0;     // first input: channels [0, c0) of pixel (b, y, x) at in0 + b*in_pb + y*in_py + x*in_px
+    const float* in1; int c1;     // optional second input (channel concat), same pitches, c1 = 0 if none
+    int in_px, in_py, in_pb;      // input pitches in floats
     const float* w;               // conv: [KH,KW,Cin,Cout]; transposed: [KH,KW,Cout,Cin]
     const float* scale;           // per-Cout affine (folded BN) or nullptr
     const float* shift;           // per-Cout shift (folded BN / bias) or nullptr
-    float* out; int out_c, out_coff;  // output pixel pitch and channel offset (for writing into a concat buffer)
+    float* out;                   // output pixel (b, y, x) channel co at out + b*out_pb + y*out_py + x*out_px + co
+    int out_px, out_py, out_pb;
     int B, Hin, Win, Hout, Wout, Cout;
     int KH, KW, stride, pad;      // pad = padding before (TF SAME)
     int transposed;

@@ -370,7 +370,7 @@ hipError_t launch_latent(const float* mv, const float* eps, float* z, int B, int
 template <int CPL>   // channels per lane, C = 64 * CPL
 __global__ void __launch_bounds__(256) head_kernel(const float* __restrict__ x, const float* __restrict__ weff,
                                                    float bias, float* __restrict__ out, int B, int r, float slope,
-                                                   int tanh_out, int seg) {
+                                                   int tanh_out, int seg, int x_py, int x_pb) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     constexpr int C = 64 * CPL;
@@ -386,13 +386,13 @@ __global__ void __launch_bounds__(256) head_kernel(const float* __restrict__ x, 
 #pragma unroll
         for (int c = 0; c < CPL; ++c) (&w[0][0][0][0][0])[a * CPL + c] = weff[(size_t)a * C + lane * CPL + c];
 
-    const float* xb = x + (size_t)b * r * r * C;
+    const float* xb = x + (size_t)b * x_pb;   // pixel (0,0) of image b; rows x_py apart (dense or zero-bordered)
     auto load = [&](int yy, int xx, float (&v)[CPL]) {
         const bool ok = yy >= 0 && yy < r && xx >= 0 && xx < r;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
             float t = 0.f;
-            if (ok) t = xb[((size_t)yy * r + xx) * C + lane * CPL + c];
+            if (ok) t = xb[(size_t)yy * x_py + (size_t)xx * C + lane * CPL + c];
             v[c] = t >= 0.f ? t : t * slope;
         }
     };
@@ -439,13 +439,14 @@ __global__ void __launch_bounds__(256) head_kernel(const float* __restrict__ x, 
 }
 
 hipError_t launch_head(const float* x, const float* weff, float bias, float* out, int B, int r, int C, float slope,
-                       int tanh_out, hipStream_t s) {
+                       int tanh_out, int x_py, int x_pb, hipStream_t s) {
+    if (x_py <= 0) { x_py = r * C; x_pb = r * r * C; }
     const int seg = r >= 64 ? 32 : r;
     const int segs = (r + seg - 1) / seg;
     const long items = (long)B * r * segs;
     const int blocks = (int)((items + 3) / 4);
-    if (C == 128) head_kernel<2><<<blocks, 256, 0, s>>>(x, weff, bias, out, B, r, slope, tanh_out, seg);
-    else if (C == 64) head_kernel<1><<<blocks, 256, 0, s>>>(x, weff, bias, out, B, r, slope, tanh_out, seg);
+    if (C == 128) head_kernel<2><<<blocks, 256, 0, s>>>(x, weff, bias, out, B, r, slope, tanh_out, seg, x_py, x_pb);
+    else if (C == 64) head_kernel<1><<<blocks, 256, 0, s>>>(x, weff, bias, out, B, r, slope, tanh_out, seg, x_py, x_pb);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -162,6 +162,21 @@ def test_pix2pix_against_oracle(Generator):
     gen.close()
 
 
+def test_pix2pix_batched_and_repeatable(Generator):
+    """B = 3 (not a power of two: the low-resolution MFMA tiles span several images and mask the tail) and a second
+    call on the same handle (the zero borders of the concat buffers must survive a forward)."""
+    from oracle import generator_ref
+    w = make_weights("pix2pix", 256, seed=77, bias_scale=0.05)
+    x = synthetic_patches(3, 256, 5)
+    gen = Generator(256, 3, variant="pix2pix", weights=w)
+    y1 = gen(x)
+    y2 = gen(x)
+    ref = generator_ref.pix2pix_call(x, w, dtype=torch.float64)
+    assert rel_linf(y1, ref) <= TOL
+    assert np.array_equal(y1, y2)
+    gen.close()
+
+
 def test_bf16x3_precision_within_tolerance(Generator):
     """MSR_FLAG_BF16X3: conv products as 3-term split-bf16 on the bf16 MFMA; everything else fp32.
     Same <= 1e-3 bar against the float64 oracle (observed ~1e-4)."""
