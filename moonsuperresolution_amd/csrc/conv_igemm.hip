@@ -21,6 +21,7 @@
 namespace msr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // K-step = BKC channels of one tap; LDS rows are BKC + 4 floats.  Both pitches (36 and 20 floats) put the 16
@@ -211,6 +212,155 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileGeo
         else conv_epilogue_body<WM, WN, MT, NT, EPI, false, RB>(p, g, acc, wm, wn, half, l31, n0, tx0, ty0, b0, stat_tile);
     } else {
         conv_epilogue_body<WM, WN, MT, NT, EPI, false, RB>(p, g, acc, wm, wn, half, l31, n0, tx0, ty0, b0, stat_tile);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Epilogue of the 16x16x32 halo kernel.  C/D map of v_mfma_f32_16x16x32_bf16: column = lane & 15,
+// row = 4 * (lane >> 4) + reg.  A wave owns tile rows 4*wm .. 4*wm+3 (sub-tile i = one row of 16 pixels) and 64
+// output columns (sub-tile j = 16 columns), so lane (c16, rg) holds pixels x = tx0 + 4*rg + reg of each of its
+// four rows.  The tile is always interior (tb == 1, r >= 16): nothing is masked.  Loads of a batch of pixels are
+// issued together before the arithmetic, as in conv_epilogue_body.
+// ------------------------------------------------------------------------------------------------------
+template <int EPI, bool SPLIT>
+__device__ __forceinline__ void halo16_epilogue_body(const ConvParams& p, f32x4 (&acc)[4][4], int wm, int wn, int lane,
+                                                     int n0, int tx0, int ty0, int b0, int stat_tile) {
+    const int c16 = lane & 15, rg = lane >> 4;
+    const int x0 = tx0 + rg * 4, y0 = ty0 + wm * 4;
+    float* const obase = p.out + (size_t)p.out_off + (size_t)b0 * p.out_pb;
+    if constexpr (EPI == EPI_SPADE) {
+        // columns come as (32 gamma | 32 beta) per 64: sub-tiles 0, 1 are gamma of channels ch0 + {0..15, 16..31},
+        // sub-tiles 2, 3 their beta twins
+        const int ch0 = (n0 + wn * 64) >> 1;
+        int ch[2];
+        float gb[2], bb[2], mu[2], sd[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int colg = n0 + wn * 64 + jj * 16 + c16;
+            ch[jj] = ch0 + jj * 16 + c16;
+            gb[jj] = p.bias[colg];
+            bb[jj] = p.bias[colg + 32];
+            mu[jj] = p.mean[ch[jj]];
+            sd[jj] = SPLIT ? 1.f / p.stdv[ch[jj]] : p.stdv[ch[jj]];
+        }
+        const float* const abase = p.aux + (size_t)b0 * p.aux_pb;
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+            float xin[2][4][2];
+            int ooff[2][4];
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int y = y0 + ib * 2 + ii, x = x0 + r;
+                    ooff[ii][r] = y * p.out_py + x * p.out_px;
+                    const float* arow = abase + (y >> p.aux_shift) * p.aux_py + (x >> p.aux_shift) * p.aux_px;
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) xin[ii][r][jj] = arow[ch[jj]];
+                }
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float* orow = obase + ooff[ii][r];
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const float gam = acc[ib * 2 + ii][jj][r] + gb[jj];
+                        const float bet = acc[ib * 2 + ii][jj + 2][r] + bb[jj];
+                        const float normalized = SPLIT ? (xin[ii][r][jj] - mu[jj]) * sd[jj] : (xin[ii][r][jj] - mu[jj]) / sd[jj];
+                        float v = gam * normalized + bet;
+                        v = v >= 0.f ? v : v * p.slope;
+                        if constexpr (SPLIT) {
+                            // 16 lanes hold half a 32-channel chunk of one pixel: neighbours pair up so that every
+                            // lane issues one 4-byte store (even lane: the hi pair, odd lane: the lo pair)
+                            unsigned hi, lo;
+                            msr_split_bf16(v, hi, lo);
+                            const unsigned nhi = lane_xor1(hi), nlo = lane_xor1(lo);
+                            unsigned* chunk = reinterpret_cast<unsigned*>(orow) + ch0;
+                            const unsigned word = (c16 & 1) ? (nlo | (lo << 16)) : (hi | (nhi << 16));
+                            chunk[((c16 & 1) ? 16 : 0) + jj * 8 + (c16 >> 1)] = word;
+                        } else {
+                            orow[ch[jj]] = v;
+                        }
+                    }
+                }
+        }
+    } else {
+        int col[4];
+        float bs[4], st_v0[4], st_s1[4], st_s2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            col[j] = n0 + wn * 64 + j * 16 + c16;
+            bs[j] = p.bias[col[j]];
+            st_v0[j] = st_s1[j] = st_s2[j] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float xin[4][4];
+            int ooff[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int y = y0 + i, x = x0 + r;
+                ooff[r] = y * p.out_py + x * p.out_px;
+                if constexpr (EPI == EPI_RES) {
+                    const float* arow = p.aux + (size_t)b0 * p.aux_pb + (y >> p.aux_shift) * p.aux_py +
+                                        (x >> p.aux_shift) * p.aux_px;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xin[r][j] = arow[col[j]];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* orow = obase + ooff[r];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc[i][j][r] + bs[j];
+                    if constexpr (EPI == EPI_RES) v += xin[r][j];
+                    orow[col[j]] = v;
+                    if (i == 0 && r == 0) st_v0[j] = v;
+                    const float d = v - st_v0[j];
+                    st_s1[j] += d;
+                    st_s2[j] += d * d;
+                }
+            }
+        }
+        if (p.stat_partial) {
+            // fused output moments: lane -> (count, mean, M2) over its 16 pixels, Chan-combined over the four lanes
+            // (rg = 0..3) that hold the same column; one slab per (m-tile, wm) as in conv_epilogue_body
+            const int slab = stat_tile * 2 + wm;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float cnt = 16.f;
+                float mean = st_v0[j] + st_s1[j] * (1.f / 16.f);
+                float m2 = st_s2[j] - st_s1[j] * st_s1[j] * (1.f / 16.f);
+#pragma unroll
+                for (int sh = 16; sh <= 32; sh <<= 1) {
+                    const float omean = __shfl_xor(mean, sh), om2 = __shfl_xor(m2, sh);
+                    const float delta = omean - mean;
+                    m2 = m2 + om2 + delta * delta * (cnt * 0.5f);
+                    mean = mean + delta * 0.5f;
+                    cnt *= 2.f;
+                }
+                if (rg == 0) {
+                    float* o = p.stat_partial + (size_t)slab * 3 * p.N + col[j];
+                    o[0] = cnt;
+                    o[p.N] = mean;
+                    o[2 * p.N] = m2 > 0.f ? m2 : 0.f;
+                }
+            }
+        }
+    }
+}
+
+template <int EPI>
+__device__ __forceinline__ void halo16_epilogue(const ConvParams& p, const TileGeom& g, f32x4 (&acc)[4][4], int wm, int wn,
+                                                int lane, int n0, int tx0, int ty0, int b0) {
+    const int stat_tile = (b0 * g.tiles_y + (ty0 >> g.th_l)) * g.tiles_x + (tx0 >> g.tw_l);
+    if constexpr (EPI == EPI_SPADE) {
+        if (p.out_split) halo16_epilogue_body<EPI, true>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile);
+        else halo16_epilogue_body<EPI, false>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile);
+    } else {
+        halo16_epilogue_body<EPI, false>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile);
     }
 }
 
@@ -649,11 +799,11 @@ conv_igemm_bf16x3(const ConvParams p, const TileGeom g) {
 // K order: chunk outer, tap inner (unrolled).  At the chunk seam: barrier, halo write, barrier.
 // LDS: 180*144 + 2*128*144 = 62.8 KB -> 2 workgroups per CU.
 // ------------------------------------------------------------------------------------------------------
-template <int EPI>
+template <int EPI, int SH>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv_igemm_bf16x3_halo(const ConvParams p, const TileGeom g) {
     constexpr int WM = 2, WN = 2, MT = 2, NT = 2;
-    constexpr int NTHR = 256, BM = 128, BN = 128, BKC = 32, BKP = 36;
+    constexpr int NTHR = 256, BM = 128, BN = 128, BKC = 32, BKP = SH ? 40 : 36;
     constexpr int TH = 8, TW = 16, HH = TH + 2, HW = TW + 2, HP = HH * HW;   // 180 halo pixels
     constexpr int H_ITEMS = (HP * 8 + NTHR - 1) / NTHR;                        // 6 16-byte items per thread
     static_assert(H_ITEMS == 6, "halo staging is written for 6 items per thread");
@@ -696,6 +846,20 @@ conv_igemm_bf16x3_halo(const ConvParams p, const TileGeom g) {
         b_goff[q] = (n0 + row) * p.Cin + seg * 4;
         b_loff[q] = row * BKP + seg * 4;
     }
+    // SH == 1: v_mfma_f32_16x16x32_bf16, lane (i = lane & 15, g = lane >> 4) holds row i, k = 8g + {0..7}
+    int a_frag16[4], b_frag16[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a_frag16[i] = ((wm * 4 + i) * HW + (lane & 15)) * BKP + 4 * (lane >> 4);
+        b_frag16[i] = ((wn * 4 + i) * 16 + (lane & 15)) * BKP + 4 * (lane >> 4);
+    }
+    f32x4 acc16[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.f;
     int a_frag[MT], b_frag[NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -772,6 +936,22 @@ conv_igemm_bf16x3_halo(const ConvParams p, const TileGeom g) {
     {                                                                                            \
         const float* a_ = Ah + (((TAP) / 3) * HW + ((TAP) % 3)) * BKP;                           \
         const float* b_ = Bs + (buf) * BN * BKP;                                                 \
+        if constexpr (SH == 1) {                                                                 \
+            bf16x8 ah[4], al[4];                                                                 \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                      \
+                ah[i] = *reinterpret_cast<const bf16x8*>(a_ + a_frag16[i]);                      \
+                al[i] = *reinterpret_cast<const bf16x8*>(a_ + a_frag16[i] + 16);                 \
+            }                                                                                    \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                      \
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b_ + b_frag16[j]);            \
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b_ + b_frag16[j] + 16);       \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                  \
+                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc16[i][j], 0, 0, 0); \
+                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc16[i][j], 0, 0, 0); \
+                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc16[i][j], 0, 0, 0); \
+                }                                                                                \
+            }                                                                                    \
+        } else                                                                                   \
         _Pragma("unroll") for (int kg = 0; kg < 2; ++kg) {                                       \
             bf16x8 ah[MT], al[MT], bh[NT], bl[NT];                                               \
             _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                     \
@@ -842,7 +1022,8 @@ conv_igemm_bf16x3_halo(const ConvParams p, const TileGeom g) {
 #undef MSR_STEP
 #undef MSR_PAIR
 
-    conv_epilogue<WM, WN, MT, NT, EPI>(p, g, acc, 0, wm, wn, half, l31, n0, tx0, ty0, b0);
+    if constexpr (SH == 1) halo16_epilogue<EPI>(p, g, acc16, wm, wn, lane, n0, tx0, ty0, b0);
+    else conv_epilogue<WM, WN, MT, NT, EPI>(p, g, acc, 0, wm, wn, half, l31, n0, tx0, ty0, b0);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -959,12 +1140,16 @@ static hipError_t set_attr_bf16x3() {
 }
 
 static constexpr size_t HALO_LDS = (size_t)(180 + 2 * 128) * 36 * sizeof(float);
+static constexpr size_t HALO16_LDS = (size_t)(180 + 2 * 128) * 40 * sizeof(float);
 
 static hipError_t set_attr_halo() {
     hipError_t e;
 #define MSR_SET(EPI)                                                                                          \
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_halo<EPI>),                  \
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_halo<EPI, 0>),               \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)HALO_LDS)) != hipSuccess)    \
+        return e;                                                                                             \
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_halo<EPI, 1>),               \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)HALO16_LDS)) != hipSuccess)  \
         return e;
     MSR_SET(EPI_BIAS) MSR_SET(EPI_RES) MSR_SET(EPI_SPADE)
 #undef MSR_SET
@@ -1164,16 +1349,25 @@ static hipError_t launch_bf16x3(const ConvParams& p, int epi, hipStream_t s) {
     return hipGetLastError();
 }
 
-static hipError_t launch_halo(const ConvParams& p, int epi, hipStream_t s) {
+static hipError_t launch_halo(const ConvParams& p, int epi, int sh, hipStream_t s) {
     TileGeom g;
     if (!make_geom(p, 128, 128, 32, g)) return hipErrorInvalidValue;
     if (g.tb != 1 || g.th_l != 3 || g.tw_l != 4 || p.stride != 1 || p.KH != 3 || p.KW != 3 || p.ksplit > 1 ||
         p.Cin % 64)   // the K loop is unrolled by two steps: 9 * (Cin / 32) must be even
         return hipErrorInvalidValue;
+    if (sh) {
+        switch (epi) {
+            case EPI_BIAS: conv_igemm_bf16x3_halo<EPI_BIAS, 1><<<g.tiles_mn, 256, HALO16_LDS, s>>>(p, g); break;
+            case EPI_RES: conv_igemm_bf16x3_halo<EPI_RES, 1><<<g.tiles_mn, 256, HALO16_LDS, s>>>(p, g); break;
+            case EPI_SPADE: conv_igemm_bf16x3_halo<EPI_SPADE, 1><<<g.tiles_mn, 256, HALO16_LDS, s>>>(p, g); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (epi) {
-        case EPI_BIAS: conv_igemm_bf16x3_halo<EPI_BIAS><<<g.tiles_mn, 256, HALO_LDS, s>>>(p, g); break;
-        case EPI_RES: conv_igemm_bf16x3_halo<EPI_RES><<<g.tiles_mn, 256, HALO_LDS, s>>>(p, g); break;
-        case EPI_SPADE: conv_igemm_bf16x3_halo<EPI_SPADE><<<g.tiles_mn, 256, HALO_LDS, s>>>(p, g); break;
+        case EPI_BIAS: conv_igemm_bf16x3_halo<EPI_BIAS, 0><<<g.tiles_mn, 256, HALO_LDS, s>>>(p, g); break;
+        case EPI_RES: conv_igemm_bf16x3_halo<EPI_RES, 0><<<g.tiles_mn, 256, HALO_LDS, s>>>(p, g); break;
+        case EPI_SPADE: conv_igemm_bf16x3_halo<EPI_SPADE, 0><<<g.tiles_mn, 256, HALO_LDS, s>>>(p, g); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1181,7 +1375,8 @@ static hipError_t launch_halo(const ConvParams& p, int epi, hipStream_t s) {
 
 hipError_t launch_conv_igemm(const ConvParams& p, int epilogue, int tile, hipStream_t s) {
     if (p.prec == PREC_BF16X3) {
-        if (tile == TILE_128x128_HALO) return launch_halo(p, epilogue, s);
+        if (tile == TILE_128x128_HALO) return launch_halo(p, epilogue, 0, s);
+        if (tile == TILE_128x128_HALO16) return launch_halo(p, epilogue, 1, s);
         if (p.wt_frag) {
             if (tile == TILE_64x64) return launch_bf16x3<2, 1, 1, 2>(p, epilogue, s);
             return launch_bf16x3<2, 2, 2, 2>(p, epilogue, s);

@@ -9,7 +9,7 @@ import torch
 from . import _lib
 
 EPI_BIAS, EPI_RES, EPI_SPADE = 0, 1, 2
-TILE_128, TILE_64, TILE_128_K16, TILE_HALO, TILE_FRAG = 0, 1, 2, 3, 0x40
+TILE_128, TILE_64, TILE_128_K16, TILE_HALO, TILE_HALO16, TILE_FRAG = 0, 1, 2, 3, 4, 0x40
 
 
 class OpContext:
@@ -95,7 +95,7 @@ def conv3x3(ctx: OpContext, x_padded: torch.Tensor, w_kl: torch.Tensor, bias: to
             out_split: bool = False) -> torch.Tensor:
     """One conv_igemm launch on torch's current stream.  x_padded [B, rout*stride+2, ., Cin].
     precision="bf16x3": x_padded must hold the split-bf16 chunk image (``split_bf16``); w_kl either the
-    split-bf16 image of the kernel layout (``split_bf16(kernel_layout(w))``; tiles 0, 1 and 3 = halo) or, with
+    split-bf16 image of the kernel layout (``split_bf16(kernel_layout(w))``; tiles 0, 1, 3 = halo and 4 = halo on the 16x16x32 MFMA) or, with
     tile | TILE_FRAG, the fragment-order weights (``weights_bf16x3``; tiles 0 and 1, weights kept in VGPRs)."""
     B, Cin = x_padded.shape[0], x_padded.shape[3]
     N = w_kl.shape[1]
