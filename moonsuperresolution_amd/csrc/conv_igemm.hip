@@ -1027,6 +1027,191 @@ conv_igemm_bf16x3_halo(const ConvParams p, const TileGeom g) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// conv_igemm_bf16x3_pp: the halo kernel as a PING-PONG pair of wave groups (512 threads, one workgroup per CU).
+//
+// With two independent 256-thread workgroups per CU the two waves of a SIMD drift into lockstep: both issue
+// their MFMAs together (the matrix pipe is per SIMD, so that is no faster than one wave) and both then sit in
+// their LDS phase together, which left the pipe ~60 % busy.  Here the two waves of a SIMD belong to ONE workgroup
+// and are held half a K-step apart by the barrier schedule:
+//     phase 2t   : group X (waves 0-3)  R(t)  LDS fragment reads, weight staging      | group Y (waves 4-7)  M(t-1)
+//     phase 2t+1 : group X              M(t)  48 x v_mfma_f32_16x16x32_bf16, registers | group Y              R(t)
+// so every SIMD always has one wave in its matrix segment and one in its memory segment (MI355X_MICROARCH.md,
+// "Two waves per SIMD", items 5 and 9).  X owns the top 8 rows of a 16 x 16 pixel tile, Y the bottom 8; both use
+// the same 128-channel weight tile.  LDS: input halo (18 x 18 pixels x 32 channels) double-buffered by chunk,
+// weight tile double-buffered by K-step, 160-byte rows: 2 * 324 * 160 + 2 * 128 * 160 = 144,640 B.
+// Hazards (b = barrier at the end of a phase): the weights of step t+1 go to Bs[(t+1)&1] during R(t) of both
+// groups (phases 2t, 2t+1); that buffer was last read in R(t-1) (phases 2t-2, 2t-1) and is next read in R(t+1)
+// (phases 2t+2, 2t+3).  The halo of chunk c+1 goes to Ah[(c+1)&1] on tap 7 of chunk c.
+// ------------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
+    constexpr int NTHR = 512, BN = 128, BKC = 32, BKP = 40;
+    constexpr int TH = 16, TW = 16, HW = TW + 2, HP = (TH + 2) * HW;          // 324 halo pixels
+    constexpr int H_ITEMS = (HP * 8 + NTHR - 1) / NTHR;                        // 6 16-byte items per thread
+    static_assert(H_ITEMS == 6, "halo staging is written for 6 items per thread");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const Ah = smem;                       // [2][HP][BKP]
+    float* const Bs = smem + 2 * HP * BKP;        // [2][BN][BKP]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;                    // 0 = X, 1 = Y (wave-uniform, scalar)
+    const int wm = (wave >> 1) & 1, wn = wave & 1;
+
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = bid % g.tiles_n;
+    int tmi = bid / g.tiles_n;
+    const int tx0 = (tmi % g.tiles_x) << 4;
+    tmi /= g.tiles_x;
+    const int ty0 = (tmi % g.tiles_y) << 4;
+    const int b0 = tmi / g.tiles_y;
+    const int n0 = tn * BN;
+
+    int h_goff[H_ITEMS], h_loff[H_ITEMS];
+#pragma unroll
+    for (int q = 0; q < H_ITEMS; ++q) {
+        int idx = tid + q * NTHR;
+        idx = idx < HP * 8 ? idx : HP * 8 - 1;    // items past the end duplicate the last one
+        const int hp = idx >> 3, seg = idx & 7;
+        const int hy = hp / HW, hx = hp - hy * HW;
+        h_goff[q] = (b0 * p.in_pb + (ty0 + hy) * p.in_py + (tx0 + hx) * p.Cin + seg * 4) * 4;
+        h_loff[q] = hp * BKP + seg * 4;
+    }
+    int b_goff[2], b_loff[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int idx = tid + q * NTHR;
+        const int row = idx >> 3, seg = idx & 7;
+        b_goff[q] = ((n0 + row) * p.Cin + seg * 4) * 4;
+        b_loff[q] = row * BKP + seg * 4;
+    }
+    int a_frag[4], b_frag[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a_frag[i] = ((grp * 8 + wm * 4 + i) * HW + (lane & 15)) * BKP + 4 * (lane >> 4);
+        b_frag[i] = ((wn * 4 + i) * 16 + (lane & 15)) * BKP + 4 * (lane >> 4);
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    const int chunks = p.Cin / BKC;               // even: the unrolled body is a PAIR of chunks
+    const unsigned w_tap_bytes = (unsigned)((size_t)p.N * p.Cin * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.in), 0, (int)((size_t)p.B * p.in_pb * sizeof(float)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.wt), 0, (int)(9u * w_tap_bytes), 0x00020000);
+    unsigned h_pair = 0, w_pair = 0;              // byte offsets of the current chunk pair
+
+    float4 rh0, rh1, rh2, rh3, rh4, rh5;          // halo of the next chunk in flight
+    float4 rw0, rw1;                              // weights of the next K-step in flight
+    bf16x8 ah[4], al[4], bh[4], bl[4];            // fragments of the current K-step
+#define MSR_BUFLD(rs, voff, soff) \
+    __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (int)(soff), 0))
+#define MSR_LOAD_H(soff)                                                                         \
+    {                                                                                            \
+        rh0 = MSR_BUFLD(rs_in, h_goff[0], soff); rh1 = MSR_BUFLD(rs_in, h_goff[1], soff);        \
+        rh2 = MSR_BUFLD(rs_in, h_goff[2], soff); rh3 = MSR_BUFLD(rs_in, h_goff[3], soff);        \
+        rh4 = MSR_BUFLD(rs_in, h_goff[4], soff); rh5 = MSR_BUFLD(rs_in, h_goff[5], soff);        \
+    }
+#define MSR_WRITE_H(buf)                                                                         \
+    {                                                                                            \
+        float* h_ = Ah + (buf) * HP * BKP;                                                       \
+        *reinterpret_cast<float4*>(h_ + h_loff[0]) = rh0; *reinterpret_cast<float4*>(h_ + h_loff[1]) = rh1; \
+        *reinterpret_cast<float4*>(h_ + h_loff[2]) = rh2; *reinterpret_cast<float4*>(h_ + h_loff[3]) = rh3; \
+        *reinterpret_cast<float4*>(h_ + h_loff[4]) = rh4; *reinterpret_cast<float4*>(h_ + h_loff[5]) = rh5; \
+    }
+// weights of K-step U of the current pair (U = 18, 19 are the first two steps of the next pair)
+#define MSR_WPTR(U) (w_pair + ((U) / 9) * (BKC * 4) + (unsigned)((U) % 9) * w_tap_bytes)
+#define MSR_LOAD_B(soff)                                                                         \
+    { rw0 = MSR_BUFLD(rs_wt, b_goff[0], soff); rw1 = MSR_BUFLD(rs_wt, b_goff[1], soff); }
+#define MSR_WRITE_B(buf)                                                                         \
+    {                                                                                            \
+        float* b_ = Bs + (buf) * BN * BKP;                                                       \
+        *reinterpret_cast<float4*>(b_ + b_loff[0]) = rw0; *reinterpret_cast<float4*>(b_ + b_loff[1]) = rw1; \
+    }
+// R(T): memory segment of K-step T (0..17 within the pair, compile time)
+#define MSR_R(T, LASTP)                                                                          \
+    {                                                                                            \
+        if (!(LASTP) || (T) + 1 < 18) MSR_WRITE_B(((T) + 1) & 1);                                \
+        if (!(LASTP) || (T) + 2 < 18) MSR_LOAD_B(MSR_WPTR((T) + 2));                             \
+        if ((T) % 9 == 1 && ((T) < 9 || !(LASTP))) MSR_LOAD_H(h_pair + ((T) / 9 + 1) * BKC * 4); \
+        if ((T) % 9 == 7 && ((T) < 9 || !(LASTP))) MSR_WRITE_H((((T) / 9) & 1) ^ 1);            \
+        const float* a_ = Ah + (((T) / 9) & 1) * HP * BKP + ((((T) % 9) / 3) * HW + (((T) % 9) % 3)) * BKP; \
+        const float* b_ = Bs + ((T) & 1) * BN * BKP;                                             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
+            ah[i] = *reinterpret_cast<const bf16x8*>(a_ + a_frag[i]);                            \
+            al[i] = *reinterpret_cast<const bf16x8*>(a_ + a_frag[i] + 16);                       \
+            bh[i] = *reinterpret_cast<const bf16x8*>(b_ + b_frag[i]);                            \
+            bl[i] = *reinterpret_cast<const bf16x8*>(b_ + b_frag[i] + 16);                       \
+        }                                                                                        \
+    }
+// M(T): matrix segment, registers only
+#define MSR_M()                                                                                  \
+    {                                                                                            \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                          \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                        \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0); \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                        \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                        \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
+        }                                                                                        \
+    }
+#define MSR_STEP(T, LASTP)                                                                       \
+    {                                                                                            \
+        MSR_R(T, LASTP)                                                                          \
+        __syncthreads();                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        MSR_M()                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if (!((LASTP) && (T) == 17) || grp == 0) __syncthreads();   /* Y's last M has no partner */ \
+    }
+#define MSR_PAIR(LASTP)                                                                          \
+    MSR_STEP(0, LASTP) MSR_STEP(1, LASTP) MSR_STEP(2, LASTP) MSR_STEP(3, LASTP) MSR_STEP(4, LASTP) \
+    MSR_STEP(5, LASTP) MSR_STEP(6, LASTP) MSR_STEP(7, LASTP) MSR_STEP(8, LASTP) MSR_STEP(9, LASTP) \
+    MSR_STEP(10, LASTP) MSR_STEP(11, LASTP) MSR_STEP(12, LASTP) MSR_STEP(13, LASTP)              \
+    MSR_STEP(14, LASTP) MSR_STEP(15, LASTP) MSR_STEP(16, LASTP) MSR_STEP(17, LASTP)
+
+    // prologue: halo of chunk 0 and the weights of step 0 into LDS, the weights of step 1 stay in flight
+    MSR_LOAD_H(h_pair);
+    MSR_LOAD_B(MSR_WPTR(0));
+    MSR_WRITE_H(0);
+    MSR_WRITE_B(0);
+    MSR_LOAD_B(MSR_WPTR(1));
+    __syncthreads();
+    if (grp == 1) __syncthreads();                // Y starts half a step late (phase 0 is X's R(0) alone)
+    for (int pr = 0; pr < chunks / 2 - 1; ++pr) {
+        MSR_PAIR(false)
+        h_pair += 2 * BKC * 4;
+        w_pair += 2 * BKC * 4;
+    }
+    MSR_PAIR(true)
+#undef MSR_BUFLD
+#undef MSR_LOAD_H
+#undef MSR_WRITE_H
+#undef MSR_WPTR
+#undef MSR_LOAD_B
+#undef MSR_WRITE_B
+#undef MSR_R
+#undef MSR_M
+#undef MSR_STEP
+#undef MSR_PAIR
+
+    TileGeom ge = g;                              // the epilogue numbers its moment slabs by 8-row tiles
+    ge.th_l = 3;
+    ge.tiles_y = g.tiles_y * 2;
+    halo16_epilogue<EPI>(p, ge, acc, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0);
+}
+
+// ------------------------------------------------------------------------------------------------------
 // splitk_epilogue: sums the ksplit partial accumulators in a fixed order (deterministic) and applies the same
 // epilogue the fused kernel would have applied.  One thread per (pixel, 4 channels).
 // ------------------------------------------------------------------------------------------------------
@@ -1142,8 +1327,16 @@ static hipError_t set_attr_bf16x3() {
 static constexpr size_t HALO_LDS = (size_t)(180 + 2 * 128) * 36 * sizeof(float);
 static constexpr size_t HALO16_LDS = (size_t)(180 + 2 * 128) * 40 * sizeof(float);
 
+static constexpr size_t PP_LDS = (size_t)(2 * 324 + 2 * 128) * 40 * sizeof(float);
+
 static hipError_t set_attr_halo() {
     hipError_t e;
+#define MSR_SETPP(EPI)                                                                                        \
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_pp<EPI>),                    \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_LDS)) != hipSuccess)      \
+        return e;
+    MSR_SETPP(EPI_BIAS) MSR_SETPP(EPI_RES) MSR_SETPP(EPI_SPADE)
+#undef MSR_SETPP
 #define MSR_SET(EPI)                                                                                          \
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_halo<EPI, 0>),               \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)HALO_LDS)) != hipSuccess)    \
@@ -1373,8 +1566,24 @@ static hipError_t launch_halo(const ConvParams& p, int epi, int sh, hipStream_t 
     return hipGetLastError();
 }
 
+static hipError_t launch_pp(const ConvParams& p, int epi, hipStream_t s) {
+    TileGeom g;
+    if (!make_geom(p, 256, 128, 32, g)) return hipErrorInvalidValue;
+    if (g.tb != 1 || g.th_l != 4 || g.tw_l != 4 || p.stride != 1 || p.KH != 3 || p.KW != 3 || p.ksplit > 1 ||
+        p.Cin % 64)
+        return hipErrorInvalidValue;
+    switch (epi) {
+        case EPI_BIAS: conv_igemm_bf16x3_pp<EPI_BIAS><<<g.tiles_mn, 512, PP_LDS, s>>>(p, g); break;
+        case EPI_RES: conv_igemm_bf16x3_pp<EPI_RES><<<g.tiles_mn, 512, PP_LDS, s>>>(p, g); break;
+        case EPI_SPADE: conv_igemm_bf16x3_pp<EPI_SPADE><<<g.tiles_mn, 512, PP_LDS, s>>>(p, g); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_conv_igemm(const ConvParams& p, int epilogue, int tile, hipStream_t s) {
     if (p.prec == PREC_BF16X3) {
+        if (tile == TILE_256x128_PP) return launch_pp(p, epilogue, s);
         if (tile == TILE_128x128_HALO) return launch_halo(p, epilogue, 0, s);
         if (tile == TILE_128x128_HALO16) return launch_halo(p, epilogue, 1, s);
         if (p.wt_frag) {

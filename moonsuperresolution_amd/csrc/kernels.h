@@ -82,7 +82,7 @@ __host__ __device__ inline void msr_store_split4(float* pixel, int c, float v0, 
     chunk[16 + w] = l0 | (l1 << 16); chunk[16 + w + 1] = l2 | (l3 << 16);
 }
 
-enum ConvTile : int { TILE_128x128 = 0, TILE_64x64 = 1, TILE_128x128_K16 = 2, TILE_128x128_HALO = 3, TILE_128x128_HALO16 = 4 };
+enum ConvTile : int { TILE_128x128 = 0, TILE_64x64 = 1, TILE_128x128_K16 = 2, TILE_128x128_HALO = 3, TILE_128x128_HALO16 = 4, TILE_256x128_PP = 5 };
 
 hipError_t conv_igemm_init();   // sets dynamic-LDS attributes once
 hipError_t launch_conv_igemm(const ConvParams& p, int epilogue, int tile, hipStream_t s);

@@ -9,7 +9,7 @@ import torch
 from . import _lib
 
 EPI_BIAS, EPI_RES, EPI_SPADE = 0, 1, 2
-TILE_128, TILE_64, TILE_128_K16, TILE_HALO, TILE_HALO16, TILE_FRAG = 0, 1, 2, 3, 4, 0x40
+TILE_128, TILE_64, TILE_128_K16, TILE_HALO, TILE_HALO16, TILE_PP, TILE_FRAG = 0, 1, 2, 3, 4, 5, 0x40
 
 
 class OpContext:

@@ -26,14 +26,14 @@ for name, r, cin, N, epi in shapes:
     std = torch.ones(C, device="cuda") if epi == 2 else None
     out = torch.zeros((B, r + 2, r + 2, C), device="cuda") if epi == 2 else torch.empty((B, r, r, C), device="cuda")
     line = f"{name:10s} r={r:4d} Cin={cin:5d} N={N:5d}"
-    for tile, prec in ((0, "fp32"), (0, "bf16x3"), (0x40, "bf16x3"), (3, "bf16x3"), (4, "bf16x3"), (1, "bf16x3"), (0x41, "bf16x3")):
+    for tile, prec in ((0, "fp32"), (0, "bf16x3"), (0x40, "bf16x3"), (3, "bf16x3"), (4, "bf16x3"), (5, "bf16x3")):
         try:
             kw = dict(epilogue=epi, aux=aux, mean=mean, std=std, out_padded=(epi == 2), tile=tile, out=out, precision=prec,
                       out_split=(epi == 2 and prec == "bf16x3"))   # as the generator runs it
             for _ in range(2):
                 ops.conv3x3(ctx, x, w, bias, r, **kw)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            n = 5
+            n = 40
             a.record()
             for _ in range(n):
                 ops.conv3x3(ctx, x, w, bias, r, **kw)

@@ -97,13 +97,14 @@ def test_untileable_shape_is_rejected(ctx):
 @pytest.mark.parametrize("B,r,cin,cout,stride,tile", [
     (2, 16, 64, 128, 1, 0), (2, 16, 64, 128, 1, 1), (3, 8, 32, 64, 1, 1), (2, 16, 64, 128, 2, 1),
     (2, 8, 128, 128, 1, 1 + 256 * 4), (16, 1, 64, 64, 1, 1), (2, 16, 64, 128, 1, 3), (1, 32, 128, 256, 1, 3),
-    (2, 16, 64, 128, 1, 4), (1, 32, 128, 256, 1, 4), (3, 16, 128, 256, 1, 4)])
+    (2, 16, 64, 128, 1, 4), (1, 32, 128, 256, 1, 4), (3, 16, 128, 256, 1, 4),
+    (2, 16, 64, 128, 1, 5), (1, 32, 128, 256, 1, 5), (3, 16, 128, 256, 1, 5)])
 def test_conv_bf16x3(ctx, B, r, cin, cout, stride, tile, frag):
     """3-term split-bf16 products, fp32 accumulation: error bound ~3*2^-18 per product -> rel L-inf <= 5e-5.
     Three kernels: LDS-staged weights (tiles 0/1), weights in VGPRs (| 0x40), LDS-staged input halo (tile 3 on the
-    32x32x16 MFMA, tile 4 on the 16x16x32 MFMA)."""
+    32x32x16 MFMA, tile 4 on the 16x16x32 MFMA, tile 5 = the 512-thread ping-pong form of tile 4)."""
     from moonsuperresolution_amd import ops
-    if frag and (tile & 0x3F) in (3, 4):
+    if frag and (tile & 0x3F) in (3, 4, 5):
         pytest.skip("the halo kernel stages its weights through LDS")
     g = torch.Generator(device="cpu").manual_seed(B * 1000 + r + 1)
     rin = r * stride
@@ -136,7 +137,7 @@ def test_split_bf16_words(ctx):
     assert float(z.abs().max()) == 0.0                                         # the zero border stays zero
 
 
-@pytest.mark.parametrize("tile", [0, 3, 4])
+@pytest.mark.parametrize("tile", [0, 3, 4, 5])
 def test_conv_spade_epilogue_bf16x3_split_output(ctx, tile):
     from moonsuperresolution_amd import ops
     g = torch.Generator(device="cpu").manual_seed(13)
