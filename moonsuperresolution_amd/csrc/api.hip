@@ -39,6 +39,7 @@ struct Op {
     bool on_aux = false;              // depends on the call's input only: runs on the handle's auxiliary stream
     hipEvent_t done = nullptr;        // recorded on the auxiliary stream after an on_aux op
     hipEvent_t wait = nullptr;        // the main stream waits for this before launching the op
+    int aux_group = -1;               // on_aux ops and their consumers: one event / one wait per group
     ConvParams conv{}; int epi = 0, tile = 0;
     int stat_slabs = 0;               // > 0: the conv's epilogue also writes partial output moments (fused)
     SmallCinParams sc{};
@@ -739,6 +740,7 @@ int plan_spade(msr_handle* h) {
             p.out_split = h->prec == PREC_BF16X3;
             em.flops = 2.0 * B * r * r * 18.0 * 128;
             em.on_aux = true;
+            em.aux_group = i <= 3 ? 0 : i - 3;   // rb1-3 are tiny: one group
             if (hipEventCreateWithFlags(&em.done, hipEventDisableTiming) != hipSuccess)
                 return fail(h, MSR_ERR_DEVICE, "hipEventCreate failed");
             h->ops.push_back(em);
@@ -749,6 +751,7 @@ int plan_spade(msr_handle* h) {
             set_aux_dense(gb.conv, x, rx, C, xshift);
             gb.conv.mean = mean; gb.conv.stdv = stdv;
             gb.wait = em.done;
+            gb.aux_group = em.aux_group;
             h->ops.push_back(gb);
             snprintf(k, sizeof k, "gen.rb%d.conv_%d.kernel", i, conv_idx); const float* cw = need(k);
             snprintf(k, sizeof k, "gen.rb%d.conv_%d.bias", i, conv_idx); const float* cb = need(k);
@@ -793,6 +796,24 @@ int plan_spade(msr_handle* h) {
         hd.head = {x_prev, need("gen.head.weff"), h->host_small["gen.head.bias"][0], B, r_prev, 128, 0.2f, 0, 0, 0};
         hd.flops = 2.0 * B * S * S * 16.0 * 128;
         h->ops.push_back(hd);
+    }
+    // A cross-stream wait stalls the main stream for ~16 us whether or not the event has fired, so the aux stream
+    // signals once per group (after the group's last mask-embedding conv; the stream is in order) and only the
+    // group's first consumer waits.
+    for (int grp = 0; grp < 4; ++grp) {
+        int last_aux = -1, first_wait = -1;
+        for (size_t k = 0; k < h->ops.size(); ++k) {
+            if (h->ops[k].aux_group != grp) continue;
+            if (h->ops[k].on_aux) last_aux = (int)k;
+            else if (first_wait < 0) first_wait = (int)k;
+        }
+        if (last_aux < 0) continue;
+        for (size_t k = 0; k < h->ops.size(); ++k) {
+            Op& op = h->ops[k];
+            if (op.aux_group != grp) continue;
+            if (op.on_aux && (int)k != last_aux) { hipEventDestroy(op.done); op.done = nullptr; }
+            if (!op.on_aux) op.wait = (int)k == first_wait ? h->ops[last_aux].done : nullptr;
+        }
     }
     mom_doubles = std::max<size_t>(mom_doubles, (size_t)32 * 3 * 1024);   // also the slab-group scratch
     HIPCHK(h, hipMalloc(&h->mom_partial, std::max<size_t>(mom_doubles, 16) * sizeof(double)));
@@ -998,7 +1019,7 @@ int msr_forward(msr_handle* h, const float* in_dev, const float* eps_dev, float*
                 p.src = in_dev;
                 hipError_t e = launch_conv_smallcin(p, h->aux);
                 if (e != hipSuccess) return fail(h, MSR_ERR_DEVICE, "launch of conv_smallcin (aux) failed: %s", hipGetErrorString(e));
-                HIPCHK(h, hipEventRecord(op.done, h->aux));
+                if (op.done) HIPCHK(h, hipEventRecord(op.done, h->aux));
             }
         }
     }
