@@ -81,11 +81,12 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("MSR_LIB", LIB_PATH)   # another build of the same ABI (A/B kernel comparisons)
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C moonsuperresolution_amd/csrc`).  moonsuperresolution_amd has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, restype, argtypes in SYMBOLS:
         fn = getattr(lib, name)   # AttributeError if the ABI lost a symbol
         fn.restype = restype

@@ -216,136 +216,147 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileGeo
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Epilogue of the 16x16x32 halo kernel.  C/D map of v_mfma_f32_16x16x32_bf16: column = lane & 15,
-// row = 4 * (lane >> 4) + reg.  A wave owns tile rows 4*wm .. 4*wm+3 (sub-tile i = one row of 16 pixels) and 64
-// output columns (sub-tile j = 16 columns), so lane (c16, rg) holds pixels x = tx0 + 4*rg + reg of each of its
-// four rows.  The tile is always interior (tb == 1, r >= 16): nothing is masked.  Loads of a batch of pixels are
-// issued together before the arithmetic, as in conv_epilogue_body.
+// Epilogue of the 16x16x32 halo kernels.  They issue the MFMA with the WEIGHT fragment as the row operand, i.e.
+// they accumulate the transposed tile D[channel][pixel]: column = lane & 15 = pixel, row = 4 * (lane >> 4) + reg =
+// channel, so a lane holds FOUR CONSECUTIVE CHANNELS of one pixel in the four registers of a sub-tile and every
+// global access below is 16 bytes (8 for the split-bf16 halves).  A dword access costs the memory pipeline the
+// same 16 cycles per wave-instruction as a 16-byte one: with one workgroup per CU the epilogue is exposed, and the
+// dword form of it was 10-30 % of the short-K layers.
+// A wave owns tile rows 4*wm .. 4*wm+3 (sub-tile i = one row of 16 pixels) and 64 output columns (sub-tile j = 16
+// columns): lane (px, cg) holds pixel x = tx0 + px of each of its four rows.  The tile is always interior
+// (tb == 1, r >= 16): nothing is masked.
 // ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 f4(const f32x4& v) { return make_float4(v[0], v[1], v[2], v[3]); }
+
+// sum over the 16 lanes of a DPP row (here: the 16 pixels of a tile row), result in every lane; 4 VALU pairs
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    return v;
+}
+
+// Everything the epilogue reads from memory, so that the ping-pong kernel can request it two K-steps before the end
+// of a tile's main loop (the staging registers are idle by then) instead of paying the latency after it:
+//   EPI_SPADE: xin[i][jj] = channels ch0 + 16*jj + 4*cg + {0..3} of x at pixel (y0 + i, x);
+//              cv = {gamma bias, beta bias, mean, sigma} x {jj = 0, 1}
+//   others   : cv[j] = bias of columns n0 + 64*wn + 16*j + 4*cg + {0..3}
+template <int EPI>
+__device__ __forceinline__ void halo16_epilogue_load(const ConvParams& p, float4 (&xin)[4][2], float4 (&cv)[8], int wm,
+                                                     int wn, int lane, int n0, int tx0, int ty0, int b0) {
+    const int px = lane & 15, cg = lane >> 4;
+    if constexpr (EPI == EPI_SPADE) {
+        const int x = tx0 + px, y0 = ty0 + wm * 4;
+        const int ch0 = (n0 + wn * 64) >> 1;
+        const float* const abase = p.aux + (size_t)b0 * p.aux_pb + (x >> p.aux_shift) * p.aux_px + ch0 + 4 * cg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* arow = abase + ((y0 + i) >> p.aux_shift) * p.aux_py;
+            xin[i][0] = *reinterpret_cast<const float4*>(arow);
+            xin[i][1] = *reinterpret_cast<const float4*>(arow + 16);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int colg = n0 + wn * 64 + jj * 16 + 4 * cg;
+            const int ch = ch0 + jj * 16 + 4 * cg;
+            cv[jj] = *reinterpret_cast<const float4*>(p.bias + colg);
+            cv[2 + jj] = *reinterpret_cast<const float4*>(p.bias + colg + 32);
+            cv[4 + jj] = *reinterpret_cast<const float4*>(p.mean + ch);
+            cv[6 + jj] = *reinterpret_cast<const float4*>(p.stdv + ch);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cv[j] = *reinterpret_cast<const float4*>(p.bias + n0 + wn * 64 + j * 16 + 4 * cg);
+    }
+}
+
 template <int EPI, bool SPLIT>
 __device__ __forceinline__ void halo16_epilogue_body(const ConvParams& p, f32x4 (&acc)[4][4], int wm, int wn, int lane,
-                                                     int n0, int tx0, int ty0, int b0, int stat_tile) {
-    const int c16 = lane & 15, rg = lane >> 4;
-    const int x0 = tx0 + rg * 4, y0 = ty0 + wm * 4;
-    float* const obase = p.out + (size_t)p.out_off + (size_t)b0 * p.out_pb;
+                                                     int n0, int tx0, int ty0, int b0, int stat_tile,
+                                                     float4 (&xin)[4][2], float4 (&cv)[8]) {
+    const int px = lane & 15, cg = lane >> 4;
+    const int x = tx0 + px, y0 = ty0 + wm * 4;
+    float* const obase = p.out + (size_t)p.out_off + (size_t)b0 * p.out_pb + x * p.out_px;
     if constexpr (EPI == EPI_SPADE) {
         // columns come as (32 gamma | 32 beta) per 64: sub-tiles 0, 1 are gamma of channels ch0 + {0..15, 16..31},
         // sub-tiles 2, 3 their beta twins
         const int ch0 = (n0 + wn * 64) >> 1;
-        int ch[2];
-        float gb[2], bb[2], mu[2], sd[2];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-            const int colg = n0 + wn * 64 + jj * 16 + c16;
-            ch[jj] = ch0 + jj * 16 + c16;
-            gb[jj] = p.bias[colg];
-            bb[jj] = p.bias[colg + 32];
-            mu[jj] = p.mean[ch[jj]];
-            sd[jj] = SPLIT ? 1.f / p.stdv[ch[jj]] : p.stdv[ch[jj]];
-        }
-        const float* const abase = p.aux + (size_t)b0 * p.aux_pb;
+            const float gq[4] = {cv[jj].x, cv[jj].y, cv[jj].z, cv[jj].w};
+            const float bq[4] = {cv[2 + jj].x, cv[2 + jj].y, cv[2 + jj].z, cv[2 + jj].w};
+            const float mq[4] = {cv[4 + jj].x, cv[4 + jj].y, cv[4 + jj].z, cv[4 + jj].w};
+            float sq[4] = {cv[6 + jj].x, cv[6 + jj].y, cv[6 + jj].z, cv[6 + jj].w};
+            if constexpr (SPLIT) {
 #pragma unroll
-        for (int ib = 0; ib < 2; ++ib) {
-            float xin[2][4][2];
-            int ooff[2][4];
+                for (int k = 0; k < 4; ++k) sq[k] = 1.f / sq[k];          // bf16x3: multiply by 1/sigma
+            }
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
+            for (int i = 0; i < 4; ++i) {
+                float* orow = obase + (y0 + i) * p.out_py;
+                const float xq[4] = {xin[i][jj].x, xin[i][jj].y, xin[i][jj].z, xin[i][jj].w};
+                float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int y = y0 + ib * 2 + ii, x = x0 + r;
-                    ooff[ii][r] = y * p.out_py + x * p.out_px;
-                    const float* arow = abase + (y >> p.aux_shift) * p.aux_py + (x >> p.aux_shift) * p.aux_px;
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) xin[ii][r][jj] = arow[ch[jj]];
+                for (int k = 0; k < 4; ++k) {
+                    const float normalized = SPLIT ? (xq[k] - mq[k]) * sq[k] : (xq[k] - mq[k]) / sq[k];
+                    const float t = (acc[i][jj][k] + gq[k]) * normalized + (acc[i][jj + 2][k] + bq[k]);
+                    v[k] = t >= 0.f ? t : t * p.slope;
                 }
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float* orow = obase + ooff[ii][r];
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        const float gam = acc[ib * 2 + ii][jj][r] + gb[jj];
-                        const float bet = acc[ib * 2 + ii][jj + 2][r] + bb[jj];
-                        const float normalized = SPLIT ? (xin[ii][r][jj] - mu[jj]) * sd[jj] : (xin[ii][r][jj] - mu[jj]) / sd[jj];
-                        float v = gam * normalized + bet;
-                        v = v >= 0.f ? v : v * p.slope;
-                        if constexpr (SPLIT) {
-                            // 16 lanes hold half a 32-channel chunk of one pixel: neighbours pair up so that every
-                            // lane issues one 4-byte store (even lane: the hi pair, odd lane: the lo pair)
-                            unsigned hi, lo;
-                            msr_split_bf16(v, hi, lo);
-                            const unsigned nhi = lane_xor1(hi), nlo = lane_xor1(lo);
-                            unsigned* chunk = reinterpret_cast<unsigned*>(orow) + ch0;
-                            const unsigned word = (c16 & 1) ? (nlo | (lo << 16)) : (hi | (nhi << 16));
-                            chunk[((c16 & 1) ? 16 : 0) + jj * 8 + (c16 >> 1)] = word;
-                        } else {
-                            orow[ch[jj]] = v;
-                        }
-                    }
+                if constexpr (SPLIT) {
+                    // chunk image of the pixel: 16 words of hi pairs, 16 words of lo pairs
+                    unsigned h01, l01, h23, l23;
+                    msr_split_bf16_pk(v[0], v[1], h01, l01);
+                    msr_split_bf16_pk(v[2], v[3], h23, l23);
+                    unsigned* chunk = reinterpret_cast<unsigned*>(orow) + ch0 + jj * 8 + 2 * cg;
+                    *reinterpret_cast<uint2*>(chunk) = make_uint2(h01, h23);
+                    *reinterpret_cast<uint2*>(chunk + 16) = make_uint2(l01, l23);
+                } else {
+                    *reinterpret_cast<float4*>(orow + ch0 + jj * 16 + 4 * cg) = make_float4(v[0], v[1], v[2], v[3]);
                 }
+            }
         }
     } else {
-        int col[4];
-        float bs[4], st_v0[4], st_s1[4], st_s2[4];
+        // Fused output moments: sums of d = v - bias (a per-channel constant shift, the same in every lane, so the
+        // 16 lanes of a column group add up directly) and d^2 over the 64 pixels of the wave.
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            col[j] = n0 + wn * 64 + j * 16 + c16;
-            bs[j] = p.bias[col[j]];
-            st_v0[j] = st_s1[j] = st_s2[j] = 0.f;
-        }
+            const int col = n0 + wn * 64 + j * 16 + 4 * cg;
+            const float bq[4] = {cv[j].x, cv[j].y, cv[j].z, cv[j].w};
+            float4 res[4];
+            if constexpr (EPI == EPI_RES) {
+                const float* abase = p.aux + (size_t)b0 * p.aux_pb + (x >> p.aux_shift) * p.aux_px + col;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float xin[4][4];
-            int ooff[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int y = y0 + i, x = x0 + r;
-                ooff[r] = y * p.out_py + x * p.out_px;
-                if constexpr (EPI == EPI_RES) {
-                    const float* arow = p.aux + (size_t)b0 * p.aux_pb + (y >> p.aux_shift) * p.aux_py +
-                                        (x >> p.aux_shift) * p.aux_px;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) xin[r][j] = arow[col[j]];
-                }
+                for (int i = 0; i < 4; ++i)
+                    res[i] = *reinterpret_cast<const float4*>(abase + ((y0 + i) >> p.aux_shift) * p.aux_py);
             }
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float* orow = obase + ooff[r];
+            for (int i = 0; i < 4; ++i) {
+                float d[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v = acc[i][j][r] + bs[j];
-                    if constexpr (EPI == EPI_RES) v += xin[r][j];
-                    orow[col[j]] = v;
-                    if (i == 0 && r == 0) st_v0[j] = v;
-                    const float d = v - st_v0[j];
-                    st_s1[j] += d;
-                    st_s2[j] += d * d;
-                }
+                for (int k = 0; k < 4; ++k) d[k] = acc[i][j][k];
+                if constexpr (EPI == EPI_RES) { d[0] += res[i].x; d[1] += res[i].y; d[2] += res[i].z; d[3] += res[i].w; }
+                *reinterpret_cast<float4*>(obase + (y0 + i) * p.out_py + col) =
+                    make_float4(d[0] + bq[0], d[1] + bq[1], d[2] + bq[2], d[3] + bq[3]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { s1[k] += d[k]; s2[k] += d[k] * d[k]; }
             }
-        }
-        if (p.stat_partial) {
-            // fused output moments: lane -> (count, mean, M2) over its 16 pixels, Chan-combined over the four lanes
-            // (rg = 0..3) that hold the same column; one slab per (m-tile, wm) as in conv_epilogue_body
-            const int slab = stat_tile * 2 + wm;
+            if (p.stat_partial) {
+                float mean[4], m2[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float cnt = 16.f;
-                float mean = st_v0[j] + st_s1[j] * (1.f / 16.f);
-                float m2 = st_s2[j] - st_s1[j] * st_s1[j] * (1.f / 16.f);
-#pragma unroll
-                for (int sh = 16; sh <= 32; sh <<= 1) {
-                    const float omean = __shfl_xor(mean, sh), om2 = __shfl_xor(m2, sh);
-                    const float delta = omean - mean;
-                    m2 = m2 + om2 + delta * delta * (cnt * 0.5f);
-                    mean = mean + delta * 0.5f;
-                    cnt *= 2.f;
+                for (int k = 0; k < 4; ++k) {
+                    const float t1 = row16_sum(s1[k]), t2 = row16_sum(s2[k]);
+                    mean[k] = bq[k] + t1 * (1.f / 64.f);
+                    const float t = t2 - t1 * t1 * (1.f / 64.f);
+                    m2[k] = t > 0.f ? t : 0.f;
                 }
-                if (rg == 0) {
-                    float* o = p.stat_partial + (size_t)slab * 3 * p.N + col[j];
-                    o[0] = cnt;
-                    o[p.N] = mean;
-                    o[2 * p.N] = m2 > 0.f ? m2 : 0.f;
+                if (px == 0) {
+                    const int slab = stat_tile * 2 + wm;       // one slab per (8-row m-tile, wm): 64 pixels
+                    float* o = p.stat_partial + (size_t)slab * 3 * p.N + col;
+                    *reinterpret_cast<float4*>(o) = make_float4(64.f, 64.f, 64.f, 64.f);
+                    *reinterpret_cast<float4*>(o + p.N) = make_float4(mean[0], mean[1], mean[2], mean[3]);
+                    *reinterpret_cast<float4*>(o + 2 * p.N) = make_float4(m2[0], m2[1], m2[2], m2[3]);
                 }
             }
         }
@@ -354,13 +365,14 @@ __device__ __forceinline__ void halo16_epilogue_body(const ConvParams& p, f32x4 
 
 template <int EPI>
 __device__ __forceinline__ void halo16_epilogue(const ConvParams& p, const TileGeom& g, f32x4 (&acc)[4][4], int wm, int wn,
-                                                int lane, int n0, int tx0, int ty0, int b0) {
+                                                int lane, int n0, int tx0, int ty0, int b0, float4 (&xin)[4][2],
+                                                float4 (&cv)[8]) {
     const int stat_tile = (b0 * g.tiles_y + (ty0 >> g.th_l)) * g.tiles_x + (tx0 >> g.tw_l);
     if constexpr (EPI == EPI_SPADE) {
-        if (p.out_split) halo16_epilogue_body<EPI, true>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile);
-        else halo16_epilogue_body<EPI, false>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile);
+        if (p.out_split) halo16_epilogue_body<EPI, true>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile, xin, cv);
+        else halo16_epilogue_body<EPI, false>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile, xin, cv);
     } else {
-        halo16_epilogue_body<EPI, false>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile);
+        halo16_epilogue_body<EPI, false>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile, xin, cv);
     }
 }
 
@@ -946,9 +958,10 @@ conv_igemm_bf16x3_halo(const ConvParams p, const TileGeom g) {
                 const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b_ + b_frag16[j]);            \
                 const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b_ + b_frag16[j] + 16);       \
                 _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                  \
-                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc16[i][j], 0, 0, 0); \
-                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc16[i][j], 0, 0, 0); \
-                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc16[i][j], 0, 0, 0); \
+                    /* weights as the row operand: D[channel][pixel], see halo16_epilogue_body */ \
+                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[i], acc16[i][j], 0, 0, 0); \
+                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[i], acc16[i][j], 0, 0, 0); \
+                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[i], acc16[i][j], 0, 0, 0); \
                 }                                                                                \
             }                                                                                    \
         } else                                                                                   \
@@ -1022,7 +1035,11 @@ conv_igemm_bf16x3_halo(const ConvParams p, const TileGeom g) {
 #undef MSR_STEP
 #undef MSR_PAIR
 
-    if constexpr (SH == 1) halo16_epilogue<EPI>(p, g, acc16, wm, wn, lane, n0, tx0, ty0, b0);
+    if constexpr (SH == 1) {
+        float4 xin[4][2], cv[8];
+        halo16_epilogue_load<EPI>(p, xin, cv, wm, wn, lane, n0, tx0, ty0, b0);
+        halo16_epilogue<EPI>(p, g, acc16, wm, wn, lane, n0, tx0, ty0, b0, xin, cv);
+    }
     else conv_epilogue<WM, WN, MT, NT, EPI>(p, g, acc, 0, wm, wn, half, l31, n0, tx0, ty0, b0);
 }
 
@@ -1061,23 +1078,42 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
     const int grp = wave >> 2;                    // 0 = X, 1 = Y (wave-uniform, scalar)
     const int wm = (wave >> 1) & 1, wn = wave & 1;
 
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = bid % g.tiles_n;
-    int tmi = bid / g.tiles_n;
-    const int tx0 = (tmi % g.tiles_x) << 4;
-    tmi /= g.tiles_x;
-    const int ty0 = (tmi % g.tiles_y) << 4;
-    const int b0 = tmi / g.tiles_y;
-    const int n0 = tn * BN;
+    // Persistent: gridDim.x (a multiple of 8, one workgroup per CU) workgroups walk all tiles.  Workgroups are
+    // dealt round-robin over the 8 XCDs, so XCD x owns a contiguous range of logical tiles (as xcd_remap) and its
+    // gridDim.x / 8 workgroups take consecutive tiles of that range in every round: the tiles in flight on an XCD
+    // share their halo (same pixels, next channel block) and weights in that XCD's L2.
+    const int slots = gridDim.x >> 3, xcd = blockIdx.x & 7;
+    const int tq = g.tiles_mn >> 3, tr = g.tiles_mn & 7;
+    const int cnt = tq + (xcd < tr ? 1 : 0);
+    const int base = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    int tile = blockIdx.x >> 3;                   // index inside the XCD's range
+    if (tile >= cnt) return;
 
-    int h_goff[H_ITEMS], h_loff[H_ITEMS];
+    // per-tile state is scalar: tile origin (pixels, channel block) and its byte offsets in the input / weights
+    int n0, tx0, ty0, b0;
+    unsigned h_tile, w_tile;
+#define MSR_DECODE(T_, N0_, TX_, TY_, B_, HT_, WT_)                                               \
+    {                                                                                            \
+        const int tn_ = (T_) % g.tiles_n;                                                        \
+        int tmi_ = (T_) / g.tiles_n;                                                             \
+        TX_ = (tmi_ % g.tiles_x) << 4;                                                           \
+        tmi_ /= g.tiles_x;                                                                       \
+        TY_ = (tmi_ % g.tiles_y) << 4;                                                           \
+        B_ = tmi_ / g.tiles_y;                                                                   \
+        N0_ = tn_ * BN;                                                                          \
+        HT_ = (unsigned)((B_) * p.in_pb + (TY_) * p.in_py + (TX_) * p.Cin) * 4u;                  \
+        WT_ = (unsigned)((N0_) * p.Cin) * 4u;                                                    \
+    }
+    MSR_DECODE(base + tile, n0, tx0, ty0, b0, h_tile, w_tile)
+
+    int h_goff[H_ITEMS], h_loff[H_ITEMS];         // tile-relative byte offsets / LDS float offsets
 #pragma unroll
     for (int q = 0; q < H_ITEMS; ++q) {
         int idx = tid + q * NTHR;
         idx = idx < HP * 8 ? idx : HP * 8 - 1;    // items past the end duplicate the last one
         const int hp = idx >> 3, seg = idx & 7;
         const int hy = hp / HW, hx = hp - hy * HW;
-        h_goff[q] = (b0 * p.in_pb + (ty0 + hy) * p.in_py + (tx0 + hx) * p.Cin + seg * 4) * 4;
+        h_goff[q] = (hy * p.in_py + hx * p.Cin + seg * 4) * 4;
         h_loff[q] = hp * BKP + seg * 4;
     }
     int b_goff[2], b_loff[2];
@@ -1085,7 +1121,7 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
     for (int q = 0; q < 2; ++q) {
         const int idx = tid + q * NTHR;
         const int row = idx >> 3, seg = idx & 7;
-        b_goff[q] = ((n0 + row) * p.Cin + seg * 4) * 4;
+        b_goff[q] = (row * p.Cin + seg * 4) * 4;
         b_loff[q] = row * BKP + seg * 4;
     }
     int a_frag[4], b_frag[4];
@@ -1095,12 +1131,6 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
         b_frag[i] = ((wn * 4 + i) * 16 + (lane & 15)) * BKP + 4 * (lane >> 4);
     }
     f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
     const int chunks = p.Cin / BKC;               // even: the unrolled body is a PAIR of chunks
     const unsigned w_tap_bytes = (unsigned)((size_t)p.N * p.Cin * sizeof(float));
@@ -1109,10 +1139,12 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
     const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.wt), 0, (int)(9u * w_tap_bytes), 0x00020000);
     unsigned h_pair = 0, w_pair = 0;              // byte offsets of the current chunk pair
+    unsigned h_next = 0, w_next = 0;              // byte offsets of the NEXT tile (of this one again on the last)
 
     float4 rh0, rh1, rh2, rh3, rh4, rh5;          // halo of the next chunk in flight
     float4 rw0, rw1;                              // weights of the next K-step in flight
     bf16x8 ah[4], al[4], bh[4], bl[4];            // fragments of the current K-step
+    float4 xpre[4][2], cpre[8];                   // the epilogue's memory operands, requested on step 16 of the last pair
 #define MSR_BUFLD(rs, voff, soff) \
     __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (int)(soff), 0))
 #define MSR_LOAD_H(soff)                                                                         \
@@ -1128,8 +1160,8 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
         *reinterpret_cast<float4*>(h_ + h_loff[2]) = rh2; *reinterpret_cast<float4*>(h_ + h_loff[3]) = rh3; \
         *reinterpret_cast<float4*>(h_ + h_loff[4]) = rh4; *reinterpret_cast<float4*>(h_ + h_loff[5]) = rh5; \
     }
-// weights of K-step U of the current pair (U = 18, 19 are the first two steps of the next pair)
-#define MSR_WPTR(U) (w_pair + ((U) / 9) * (BKC * 4) + (unsigned)((U) % 9) * w_tap_bytes)
+// weights of K-step U of a chunk pair, relative to the pair's first chunk
+#define MSR_WOFF(U) (((U) / 9) * (BKC * 4) + (unsigned)((U) % 9) * w_tap_bytes)
 #define MSR_LOAD_B(soff)                                                                         \
     { rw0 = MSR_BUFLD(rs_wt, b_goff[0], soff); rw1 = MSR_BUFLD(rs_wt, b_goff[1], soff); }
 #define MSR_WRITE_B(buf)                                                                         \
@@ -1137,13 +1169,20 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
         float* b_ = Bs + (buf) * BN * BKP;                                                       \
         *reinterpret_cast<float4*>(b_ + b_loff[0]) = rw0; *reinterpret_cast<float4*>(b_ + b_loff[1]) = rw1; \
     }
-// R(T): memory segment of K-step T (0..17 within the pair, compile time)
+// R(T): memory segment of K-step T (0..17 within the pair, compile time).  The staging never stops: on the last
+// pair of a tile (LASTP) the steps past its end are the first steps of the NEXT tile (weights of its steps 0 and
+// 1, halo of its chunk 0), so no load or LDS write sits under a run-time condition; on the last tile of the
+// workgroup "next" is the tile itself and the staged data is simply never read.
 #define MSR_R(T, LASTP)                                                                          \
     {                                                                                            \
-        if (!(LASTP) || (T) + 1 < 18) MSR_WRITE_B(((T) + 1) & 1);                                \
-        if (!(LASTP) || (T) + 2 < 18) MSR_LOAD_B(MSR_WPTR((T) + 2));                             \
-        if ((T) % 9 == 1 && ((T) < 9 || !(LASTP))) MSR_LOAD_H(h_pair + ((T) / 9 + 1) * BKC * 4); \
-        if ((T) % 9 == 7 && ((T) < 9 || !(LASTP))) MSR_WRITE_H((((T) / 9) & 1) ^ 1);            \
+        MSR_WRITE_B(((T) + 1) & 1);                                                              \
+        if ((LASTP) && (T) + 2 >= 18) MSR_LOAD_B(w_next + MSR_WOFF((T) + 2 - 18))                \
+        else MSR_LOAD_B(w_tile + w_pair + MSR_WOFF((T) + 2));                                    \
+        if ((T) % 9 == 1) {                                                                      \
+            if ((LASTP) && (T) >= 9) MSR_LOAD_H(h_next)                                          \
+            else MSR_LOAD_H(h_tile + h_pair + ((T) / 9 + 1) * BKC * 4);                          \
+        }                                                                                        \
+        if ((T) % 9 == 7) MSR_WRITE_H((((T) / 9) & 1) ^ 1);                                      \
         const float* a_ = Ah + (((T) / 9) & 1) * HP * BKP + ((((T) % 9) / 3) * HW + (((T) % 9) % 3)) * BKP; \
         const float* b_ = Bs + ((T) & 1) * BN * BKP;                                             \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
@@ -1153,26 +1192,28 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
             bl[i] = *reinterpret_cast<const bf16x8*>(b_ + b_frag[i] + 16);                       \
         }                                                                                        \
     }
-// M(T): matrix segment, registers only
+// M(T): matrix segment, registers only (weights as the row operand: D[channel][pixel])
 #define MSR_M()                                                                                  \
     {                                                                                            \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                          \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                        \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0); \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0); \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                        \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0); \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                        \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0); \
         }                                                                                        \
     }
 #define MSR_STEP(T, LASTP)                                                                       \
     {                                                                                            \
         MSR_R(T, LASTP)                                                                          \
+        if ((LASTP) && (T) == 16) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0); \
         __syncthreads();                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         MSR_M()                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        if (!((LASTP) && (T) == 17) || grp == 0) __syncthreads();   /* Y's last M has no partner */ \
+        /* Y's M on the workgroup's very last step has no partner segment */                     \
+        if (!((LASTP) && (T) == 17) || has_next || grp == 0) __syncthreads();                    \
     }
 #define MSR_PAIR(LASTP)                                                                          \
     MSR_STEP(0, LASTP) MSR_STEP(1, LASTP) MSR_STEP(2, LASTP) MSR_STEP(3, LASTP) MSR_STEP(4, LASTP) \
@@ -1180,35 +1221,57 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
     MSR_STEP(10, LASTP) MSR_STEP(11, LASTP) MSR_STEP(12, LASTP) MSR_STEP(13, LASTP)              \
     MSR_STEP(14, LASTP) MSR_STEP(15, LASTP) MSR_STEP(16, LASTP) MSR_STEP(17, LASTP)
 
-    // prologue: halo of chunk 0 and the weights of step 0 into LDS, the weights of step 1 stay in flight
-    MSR_LOAD_H(h_pair);
-    MSR_LOAD_B(MSR_WPTR(0));
+    // prologue of the workgroup's first tile: halo of chunk 0 and the weights of step 0 into LDS, the weights of
+    // step 1 stay in flight
+    MSR_LOAD_H(h_tile);
+    MSR_LOAD_B(w_tile + MSR_WOFF(0));
     MSR_WRITE_H(0);
     MSR_WRITE_B(0);
-    MSR_LOAD_B(MSR_WPTR(1));
+    MSR_LOAD_B(w_tile + MSR_WOFF(1));
     __syncthreads();
     if (grp == 1) __syncthreads();                // Y starts half a step late (phase 0 is X's R(0) alone)
-    for (int pr = 0; pr < chunks / 2 - 1; ++pr) {
-        MSR_PAIR(false)
-        h_pair += 2 * BKC * 4;
-        w_pair += 2 * BKC * 4;
+    TileGeom ge = g;                              // the epilogue numbers its moment slabs by 8-row tiles
+    ge.th_l = 3;
+    ge.tiles_y = g.tiles_y * 2;
+    for (;;) {
+        const int tnext = tile + slots;
+        const bool has_next = tnext < cnt;
+        int n0n, tx0n, ty0n, b0n;
+        MSR_DECODE(base + (has_next ? tnext : tile), n0n, tx0n, ty0n, b0n, h_next, w_next)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+        h_pair = 0;
+        w_pair = 0;
+        for (int pr = 0; pr < chunks / 2 - 1; ++pr) {
+            MSR_PAIR(false)
+            h_pair += 2 * BKC * 4;
+            w_pair += 2 * BKC * 4;
+        }
+        MSR_PAIR(true)
+        // The epilogue of a tile shares a barrier interval with R(0) of the next one: X runs it beside Y's last M,
+        // Y beside X's first M of the next tile.  Its stores are not waited for.
+        halo16_epilogue<EPI>(p, ge, acc, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0, xpre, cpre);
+        if (!has_next) break;
+        tile = tnext;
+        n0 = n0n; tx0 = tx0n; ty0 = ty0n; b0 = b0n;
+        h_tile = h_next;
+        w_tile = w_next;
     }
-    MSR_PAIR(true)
+#undef MSR_DECODE
 #undef MSR_BUFLD
 #undef MSR_LOAD_H
 #undef MSR_WRITE_H
-#undef MSR_WPTR
+#undef MSR_WOFF
 #undef MSR_LOAD_B
 #undef MSR_WRITE_B
 #undef MSR_R
 #undef MSR_M
 #undef MSR_STEP
 #undef MSR_PAIR
-
-    TileGeom ge = g;                              // the epilogue numbers its moment slabs by 8-row tiles
-    ge.th_l = 3;
-    ge.tiles_y = g.tiles_y * 2;
-    halo16_epilogue<EPI>(p, ge, acc, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1274,7 +1337,7 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(const ConvParams p
             }
         }
         float* opix = p.out + (size_t)p.out_off + (size_t)b * p.out_pb + (size_t)y * p.out_py + (size_t)x * p.out_px;
-        if (EPI == EPI_SPADE && p.out_split) msr_store_split4(opix, c, v.x, v.y, v.z, v.w);
+        if (EPI == EPI_SPADE && p.out_split) msr_store_split4_dev(opix, c, v.x, v.y, v.z, v.w);
         else *reinterpret_cast<float4*>(opix + c) = v;
     }
 }
@@ -1572,10 +1635,20 @@ static hipError_t launch_pp(const ConvParams& p, int epi, hipStream_t s) {
     if (g.tb != 1 || g.th_l != 4 || g.tw_l != 4 || p.stride != 1 || p.KH != 3 || p.KW != 3 || p.ksplit > 1 ||
         p.Cin % 64)
         return hipErrorInvalidValue;
+    // persistent: one workgroup per CU (144 KB of LDS each), a multiple of 8 so that every XCD gets the same count
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidValue;
+        n_cu = prop.multiProcessorCount & ~7;
+        if (n_cu < 8) n_cu = 8;
+    }
+    const int grid = g.tiles_mn < n_cu ? ((g.tiles_mn + 7) & ~7) : n_cu;
     switch (epi) {
-        case EPI_BIAS: conv_igemm_bf16x3_pp<EPI_BIAS><<<g.tiles_mn, 512, PP_LDS, s>>>(p, g); break;
-        case EPI_RES: conv_igemm_bf16x3_pp<EPI_RES><<<g.tiles_mn, 512, PP_LDS, s>>>(p, g); break;
-        case EPI_SPADE: conv_igemm_bf16x3_pp<EPI_SPADE><<<g.tiles_mn, 512, PP_LDS, s>>>(p, g); break;
+        case EPI_BIAS: conv_igemm_bf16x3_pp<EPI_BIAS><<<grid, 512, PP_LDS, s>>>(p, g); break;
+        case EPI_RES: conv_igemm_bf16x3_pp<EPI_RES><<<grid, 512, PP_LDS, s>>>(p, g); break;
+        case EPI_SPADE: conv_igemm_bf16x3_pp<EPI_SPADE><<<grid, 512, PP_LDS, s>>>(p, g); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

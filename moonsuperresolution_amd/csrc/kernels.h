@@ -82,6 +82,25 @@ __host__ __device__ inline void msr_store_split4(float* pixel, int c, float v0, 
     chunk[16 + w] = l0 | (l1 << 16); chunk[16 + w + 1] = l2 | (l3 << 16);
 }
 
+// Device form on the hardware converter: v_cvt_pk_bf16_f32 rounds two fp32 to a packed bf16 pair (RNE, the same
+// bits as msr_bf16_rn for finite values), so a pair costs 5 VALU instructions instead of ~28.
+typedef __bf16 msr_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float msr_f32x2 __attribute__((ext_vector_type(2)));
+__device__ inline void msr_split_bf16_pk(float v0, float v1, unsigned& hiw, unsigned& low) {
+    const msr_f32x2 v = {v0, v1};
+    hiw = __builtin_bit_cast(unsigned, __builtin_convertvector(v, msr_bf16x2));
+    const msr_f32x2 hf = {__builtin_bit_cast(float, hiw << 16), __builtin_bit_cast(float, hiw & 0xFFFF0000u)};
+    low = __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, msr_bf16x2));
+}
+__device__ inline void msr_store_split4_dev(float* pixel, int c, float v0, float v1, float v2, float v3) {
+    unsigned h01, l01, h23, l23;
+    msr_split_bf16_pk(v0, v1, h01, l01);
+    msr_split_bf16_pk(v2, v3, h23, l23);
+    unsigned* chunk = reinterpret_cast<unsigned*>(pixel) + (c & ~31) + ((c & 31) >> 1);
+    *reinterpret_cast<uint2*>(chunk) = make_uint2(h01, h23);
+    *reinterpret_cast<uint2*>(chunk + 16) = make_uint2(l01, l23);
+}
+
 enum ConvTile : int { TILE_128x128 = 0, TILE_64x64 = 1, TILE_128x128_K16 = 2, TILE_128x128_HALO = 3, TILE_128x128_HALO16 = 4, TILE_256x128_PP = 5 };
 
 hipError_t conv_igemm_init();   // sets dynamic-LDS attributes once

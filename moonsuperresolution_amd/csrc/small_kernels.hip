@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) conv_smallcin_kernel(const SmallCinParams
                 acc.x = acc.x >= 0.f ? acc.x : acc.x * p.slope; acc.y = acc.y >= 0.f ? acc.y : acc.y * p.slope;
                 acc.z = acc.z >= 0.f ? acc.z : acc.z * p.slope; acc.w = acc.w >= 0.f ? acc.w : acc.w * p.slope;
             }
-            if (p.out_split) msr_store_split4(o + (size_t)i * p.out_px, q * 4, acc.x, acc.y, acc.z, acc.w);
+            if (p.out_split) msr_store_split4_dev(o + (size_t)i * p.out_px, q * 4, acc.x, acc.y, acc.z, acc.w);
             else *reinterpret_cast<float4*>(o + (size_t)i * p.out_px + q * 4) = acc;
         }
     }
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(256) split_bf16_kernel(const float* __restrict
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < quads; i += (long)gridDim.x * 256) {
         const float4 v = *reinterpret_cast<const float4*>(in + i * 4);
         const long e = i * 4;
-        msr_store_split4(out + (e & ~31L), (int)(e & 31), v.x, v.y, v.z, v.w);
+        msr_store_split4_dev(out + (e & ~31L), (int)(e & 31), v.x, v.y, v.z, v.w);
     }
 }
 hipError_t launch_split_bf16(const float* in, float* out, long n, hipStream_t s) {
@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(256) norm_act_kernel(const NormActParams p) {
         r.x = r.x >= 0.f ? r.x : r.x * p.slope; r.y = r.y >= 0.f ? r.y : r.y * p.slope;
         r.z = r.z >= 0.f ? r.z : r.z * p.slope; r.w = r.w >= 0.f ? r.w : r.w * p.slope;
         float* o = p.out + (size_t)p.out_off + (size_t)b * p.out_pb + (size_t)y * p.out_py + (size_t)x * p.out_px;
-        if (p.out_split) msr_store_split4(o, q * 4, r.x, r.y, r.z, r.w);
+        if (p.out_split) msr_store_split4_dev(o, q * 4, r.x, r.y, r.z, r.w);
         else *reinterpret_cast<float4*>(o + q * 4) = r;
     }
 }
