@@ -625,7 +625,7 @@ int plan_spade(msr_handle* h) {
     int rc;
     auto need = [&](const std::string& k) -> float* { return D(h, k); };
     size_t mom_doubles = 0;
-    auto mom_need = [&](int G, int P, int C) { mom_doubles = std::max(mom_doubles, (size_t)G * moments_chunks(P) * C * 2); };
+    auto mom_need = [&](int G, int P, int C) { mom_doubles = std::max(mom_doubles, (size_t)G * moments_chunks(G, P) * C * 2); };
 
     // ---------------- encoder (networks.py:8-34) ----------------
     Padded e_in;   // input of the next strided conv

@@ -138,8 +138,8 @@ hipError_t launch_split_bf16(const float* in, float* out, long n, hipStream_t s)
 
 // Per-group, per-channel moments of x [G, P, C]: mean and sqrt(var_biased + eps) (fp64 accumulation).
 //   G=1 -> tf.nn.moments over (N,H,W) (spade.py:21);  G=B -> tfa InstanceNormalization (blocks.py:63).
-// partial must hold G * chunks * C * 2 doubles with chunks = moments_chunks(P).
-int moments_chunks(int P);
+// partial must hold G * chunks * C * 2 doubles with chunks = moments_chunks(G, P).
+int moments_chunks(int G, int P);
 hipError_t launch_moments(const float* x, int G, int P, int C, float eps, double* partial, float* mean,
                           float* stdv, hipStream_t s);
 

@@ -123,18 +123,27 @@ hipError_t launch_split_bf16(const float* in, float* out, long n, hipStream_t s)
 // squares (exact to fp64 rounding, so the one-pass form equals TF's two-pass moments at fp32 precision).
 // Stage 1: grid (chunks, G); thread = (channel quad, pixel slot); Stage 2: one thread per (g, c).
 // ------------------------------------------------------------------------------------------------
-static constexpr int MOM_PIX_PER_CHUNK = 128;   // small chunks: thousands of workgroups keep enough bytes in flight
-
-int moments_chunks(int P) { return (P + MOM_PIX_PER_CHUNK - 1) / MOM_PIX_PER_CHUNK; }
+// Pixels per stage-1 workgroup: 128 for the big tensors (thousands of workgroups keep enough bytes in flight); the
+// low-resolution tensors (a few hundred pixels) take smaller chunks so that at least ~256 workgroups exist —
+// with 2 workgroups of 128 pixels the kernel was one 20 us latency chain.
+static int moments_chunk_pixels(int G, int P) {
+    int px = 128;
+    while (px > 8 && (long)G * ((P + px - 1) / px) < 256) px >>= 1;
+    return px;
+}
+int moments_chunks(int G, int P) {
+    const int px = moments_chunk_pixels(G, P);
+    return (P + px - 1) / px;
+}
 
 __global__ void __launch_bounds__(256) moments_partial_kernel(const float* __restrict__ x, int P, int C,
-                                                              double* __restrict__ partial) {
+                                                              int chunk_px, double* __restrict__ partial) {
     // partial layout: [G][chunks][C][2]
     __shared__ double red[256 * 8];
     const int quads = C / 4;
     const int chunk = blockIdx.x, g = blockIdx.y, chunks = gridDim.x;
-    const int p0 = chunk * MOM_PIX_PER_CHUNK;
-    const int p1 = min(P, p0 + MOM_PIX_PER_CHUNK);
+    const int p0 = chunk * chunk_px;
+    const int p1 = min(P, p0 + chunk_px);
     const float* xg = x + (size_t)g * P * C;
     for (int qb = 0; qb < quads; qb += 256) {
         // layout A (quads >= 256): every thread one quad, all pixels.  layout B: several pixel slots per quad.
@@ -214,8 +223,8 @@ __global__ void __launch_bounds__(1024) moments_final_kernel(const double* __res
 hipError_t launch_moments(const float* x, int G, int P, int C, float eps, double* partial, float* mean, float* stdv,
                           hipStream_t s) {
     if (C % 32) return hipErrorInvalidValue;
-    const int chunks = moments_chunks(P);
-    moments_partial_kernel<<<dim3(chunks, G), 256, 0, s>>>(x, P, C, partial);
+    const int chunks = moments_chunks(G, P);
+    moments_partial_kernel<<<dim3(chunks, G), 256, 0, s>>>(x, P, C, moments_chunk_pixels(G, P), partial);
     moments_final_kernel<<<G * (C / 32), 1024, 0, s>>>(partial, G, chunks, C, P, eps, mean, stdv);
     return hipGetLastError();
 }
@@ -271,10 +280,10 @@ static constexpr int DENSE_KCH = 256;   // largest K chunk (LDS staging of x)
 static constexpr int DENSE_MAXB = 16;
 
 static int dense_kch(int K, int N) {
-    // enough workgroups to pull the weight matrix at HBM rate: >= 512 blocks of 128 threads
+    // enough workgroups to pull the weight matrix at HBM rate: >= 1024 blocks of 128 threads, 8 loads in flight each
     const int gx = (N / 4 + 127) / 128;
     int kch = DENSE_KCH;
-    while (kch > 16 && (long)gx * ((K + kch - 1) / kch) < 512) kch >>= 1;
+    while (kch > 16 && (long)gx * ((K + kch - 1) / kch) < 1024) kch >>= 1;
     return kch;
 }
 size_t dense_partial_floats(int B, int K, int N) {
@@ -299,7 +308,7 @@ __global__ void __launch_bounds__(128) dense_partial_kernel(const float* __restr
 #pragma unroll
     for (int b = 0; b < DENSE_MAXB; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* wp = W + (size_t)k0 * N + col;
-#pragma unroll 4
+#pragma unroll 8
     for (int k = 0; k < kn; ++k) {
         const float4 w = *reinterpret_cast<const float4*>(wp + (size_t)k * N);
 #pragma unroll
@@ -364,90 +373,76 @@ hipError_t launch_latent(const float* mv, const float* eps, float* z, int B, int
 // with summed ("effective") taps; TF SAME for k=4 pads 1 before / 2 after, and out-of-range in the
 // up-sampled image is exactly out-of-range at half resolution, so zero padding carries over.
 //   weff [py][px][dy+1][dx+1][C]  (zero where a tap does not exist)
-// A wave owns one half-resolution row segment; lanes split the C channels (2 each for C=128), keep the
-// 25 live effective taps in registers, slide a 3x3 window along x and reduce across the wave.
+// One thread = one half-resolution pixel = a 2x2 block of outputs.  A workgroup stages its 16 x 16 pixel tile plus
+// the one-pixel halo through LDS 16 channels at a time (leaky-relu applied once, on the way in; out-of-range
+// pixels are zero) and every thread accumulates its 25 live taps from there; the tap weights are wave-uniform
+// (scalar loads).  HBM-bound: the half-resolution tensor is read once (x 324/256 for the halo).
 // ------------------------------------------------------------------------------------------------
-template <int CPL>   // channels per lane, C = 64 * CPL
 __global__ void __launch_bounds__(256) head_kernel(const float* __restrict__ x, const float* __restrict__ weff,
-                                                   float bias, float* __restrict__ out, int B, int r, float slope,
-                                                   int tanh_out, int seg, int x_py, int x_pb) {
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    constexpr int C = 64 * CPL;
-    const int segs = (r + seg - 1) / seg;
-    const long item = (long)blockIdx.x * 4 + wave;   // (b, i, segment)
-    if (item >= (long)B * r * segs) return;
-    const int sg = (int)(item % segs);
-    const int i = (int)((item / segs) % r);
-    const int b = (int)(item / ((long)segs * r));
-    float w[2][2][3][3][CPL];
-#pragma unroll
-    for (int a = 0; a < 36; ++a)
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) (&w[0][0][0][0][0])[a * CPL + c] = weff[(size_t)a * C + lane * CPL + c];
-
-    const float* xb = x + (size_t)b * x_pb;   // pixel (0,0) of image b; rows x_py apart (dense or zero-bordered)
-    auto load = [&](int yy, int xx, float (&v)[CPL]) {
-        const bool ok = yy >= 0 && yy < r && xx >= 0 && xx < r;
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            float t = 0.f;
-            if (ok) t = xb[(size_t)yy * x_py + (size_t)xx * C + lane * CPL + c];
-            v[c] = t >= 0.f ? t : t * slope;
+                                                   float bias, float* __restrict__ out, int B, int r, int C,
+                                                   float slope, int tanh_out, int x_py, int x_pb) {
+    constexpr int HW = 18, HP = HW * HW, CH = 16, PITCH = CH + 4;
+    __shared__ __attribute__((aligned(16))) float tile[HP * PITCH];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int tiles = r >> 4;
+    int t = blockIdx.x;
+    const int tx0 = (t % tiles) << 4;
+    t /= tiles;
+    const int ty0 = (t % tiles) << 4;
+    const int b = t / tiles;
+    const float* xb = x + (size_t)b * x_pb;
+    float o00 = 0.f, o01 = 0.f, o10 = 0.f, o11 = 0.f;
+    for (int cc = 0; cc < C; cc += CH) {
+        __syncthreads();
+        for (int it = threadIdx.x; it < HP * (CH / 4); it += 256) {
+            const int hp = it >> 2, seg = it & 3;
+            const int hy = hp / HW, hx = hp - hy * HW;
+            const int yy = ty0 + hy - 1, xx = tx0 + hx - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (yy >= 0 && yy < r && xx >= 0 && xx < r) {
+                v = *reinterpret_cast<const float4*>(xb + (size_t)yy * x_py + (size_t)xx * C + cc + seg * 4);
+                v.x = v.x >= 0.f ? v.x : v.x * slope; v.y = v.y >= 0.f ? v.y : v.y * slope;
+                v.z = v.z >= 0.f ? v.z : v.z * slope; v.w = v.w >= 0.f ? v.w : v.w * slope;
+            }
+            *reinterpret_cast<float4*>(tile + hp * PITCH + seg * 4) = v;
         }
-    };
-    const int j0 = sg * seg, j1 = min(r, j0 + seg);
-    float win[3][3][CPL];
+        __syncthreads();
+        const float* wc = weff + cc;
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-        load(i + dy - 1, j0 - 1, win[dy][1]);
-        load(i + dy - 1, j0, win[dy][2]);
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const float* tp = tile + ((ty + dy) * HW + tx + dx) * PITCH;
+#pragma unroll
+                for (int sg = 0; sg < CH / 4; ++sg) {
+                    const float4 v = *reinterpret_cast<const float4*>(tp + sg * 4);
+                    // parity 0 uses offsets {-1,0,+1} (dy, dx = 0..2), parity 1 uses {0,+1} (1..2)
+                    const float* w00 = wc + (size_t)((0 * 3 + dy) * 3 + dx) * C + sg * 4;
+                    const float* w01 = wc + (size_t)((1 * 3 + dy) * 3 + dx) * C + sg * 4;
+                    const float* w10 = wc + (size_t)((2 * 3 + dy) * 3 + dx) * C + sg * 4;
+                    const float* w11 = wc + (size_t)((3 * 3 + dy) * 3 + dx) * C + sg * 4;
+                    o00 = fmaf(v.w, w00[3], fmaf(v.z, w00[2], fmaf(v.y, w00[1], fmaf(v.x, w00[0], o00))));
+                    if (dx > 0) o01 = fmaf(v.w, w01[3], fmaf(v.z, w01[2], fmaf(v.y, w01[1], fmaf(v.x, w01[0], o01))));
+                    if (dy > 0) o10 = fmaf(v.w, w10[3], fmaf(v.z, w10[2], fmaf(v.y, w10[1], fmaf(v.x, w10[0], o10))));
+                    if (dy > 0 && dx > 0)
+                        o11 = fmaf(v.w, w11[3], fmaf(v.z, w11[2], fmaf(v.y, w11[1], fmaf(v.x, w11[0], o11))));
+                }
+            }
     }
+    o00 += bias; o01 += bias; o10 += bias; o11 += bias;
+    if (tanh_out) { o00 = tanhf(o00); o01 = tanhf(o01); o10 = tanhf(o10); o11 = tanhf(o11); }
     const int S2 = 2 * r;
-    for (int j = j0; j < j1; ++j) {
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) { win[dy][0][c] = win[dy][1][c]; win[dy][1][c] = win[dy][2][c]; }
-            load(i + dy - 1, j + 1, win[dy][2]);
-        }
-        float o[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-#pragma unroll
-        for (int py = 0; py < 2; ++py)
-#pragma unroll
-            for (int px = 0; px < 2; ++px)
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        // parity 0 uses offsets {-1,0,+1}, parity 1 uses {0,+1}
-                        if ((py == 1 && dy == 0) || (px == 1 && dx == 0)) continue;
-#pragma unroll
-                        for (int c = 0; c < CPL; ++c) o[py][px] += win[dy][dx][c] * w[py][px][dy][dx][c];
-                    }
-#pragma unroll
-        for (int py = 0; py < 2; ++py)
-#pragma unroll
-            for (int px = 0; px < 2; ++px) o[py][px] = wave_sum(o[py][px]);
-        if (lane < 4) {
-            const int py = lane >> 1, px = lane & 1;
-            float v = (py ? (px ? o[1][1] : o[1][0]) : (px ? o[0][1] : o[0][0])) + bias;
-            if (tanh_out) v = tanhf(v);
-            out[((size_t)b * S2 + 2 * i + py) * S2 + 2 * j + px] = v;
-        }
-    }
+    float* ob = out + ((size_t)b * S2 + 2 * (ty0 + ty)) * S2 + 2 * (tx0 + tx);
+    *reinterpret_cast<float2*>(ob) = make_float2(o00, o01);
+    *reinterpret_cast<float2*>(ob + S2) = make_float2(o10, o11);
 }
 
 hipError_t launch_head(const float* x, const float* weff, float bias, float* out, int B, int r, int C, float slope,
                        int tanh_out, int x_py, int x_pb, hipStream_t s) {
     if (x_py <= 0) { x_py = r * C; x_pb = r * r * C; }
-    const int seg = r >= 64 ? 32 : r;
-    const int segs = (r + seg - 1) / seg;
-    const long items = (long)B * r * segs;
-    const int blocks = (int)((items + 3) / 4);
-    if (C == 128) head_kernel<2><<<blocks, 256, 0, s>>>(x, weff, bias, out, B, r, slope, tanh_out, seg, x_py, x_pb);
-    else if (C == 64) head_kernel<1><<<blocks, 256, 0, s>>>(x, weff, bias, out, B, r, slope, tanh_out, seg, x_py, x_pb);
-    else return hipErrorInvalidValue;
+    if (r % 16 || C % 16) return hipErrorInvalidValue;
+    const int blocks = B * (r / 16) * (r / 16);
+    head_kernel<<<blocks, 256, 0, s>>>(x, weff, bias, out, B, r, C, slope, tanh_out, x_py, x_pb);
     return hipGetLastError();
 }
 
