@@ -294,13 +294,14 @@ size_t dense_partial_floats(int B, int K, int N) {
 __global__ void __launch_bounds__(128) dense_partial_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                             float* __restrict__ partial, int B, int K, int N,
                                                             int kch) {
-    __shared__ float xs[DENSE_MAXB][DENSE_KCH];
+    // x chunk as [k][16 rows]: the 16 row values of one k are four broadcast 16-byte LDS reads
+    __shared__ __attribute__((aligned(16))) float xs[DENSE_KCH * DENSE_MAXB];
     const int col = (blockIdx.x * 128 + threadIdx.x) * 4;
     const int k0 = blockIdx.y * kch;
     const int kn = min(kch, K - k0);
-    for (int i = threadIdx.x; i < B * kch; i += 128) {
+    for (int i = threadIdx.x; i < DENSE_MAXB * kch; i += 128) {
         const int b = i / kch, k = i % kch;
-        xs[b][k] = k < kn ? x[(size_t)b * K + k0 + k] : 0.f;
+        xs[k * DENSE_MAXB + b] = (b < B && k < kn) ? x[(size_t)b * K + k0 + k] : 0.f;
     }
     __syncthreads();
     if (col >= N) return;
@@ -312,10 +313,14 @@ __global__ void __launch_bounds__(128) dense_partial_kernel(const float* __restr
     for (int k = 0; k < kn; ++k) {
         const float4 w = *reinterpret_cast<const float4*>(wp + (size_t)k * N);
 #pragma unroll
-        for (int b = 0; b < DENSE_MAXB; ++b) {
-            if (b < B) {
-                const float xv = xs[b][k];
-                acc[b].x += xv * w.x; acc[b].y += xv * w.y; acc[b].z += xv * w.z; acc[b].w += xv * w.w;
+        for (int bq = 0; bq < DENSE_MAXB / 4; ++bq) {
+            const float4 xv = *reinterpret_cast<const float4*>(xs + k * DENSE_MAXB + bq * 4);
+            const float xr[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float4& a = acc[bq * 4 + e];
+                a.x = fmaf(xr[e], w.x, a.x); a.y = fmaf(xr[e], w.y, a.y);
+                a.z = fmaf(xr[e], w.z, a.z); a.w = fmaf(xr[e], w.w, a.w);
             }
         }
     }
@@ -392,21 +397,38 @@ __global__ void __launch_bounds__(256) head_kernel(const float* __restrict__ x, 
     const int b = t / tiles;
     const float* xb = x + (size_t)b * x_pb;
     float o00 = 0.f, o01 = 0.f, o10 = 0.f, o11 = 0.f;
+    // staging items of this thread (6 x 16 bytes per 16-channel chunk), fetched one chunk ahead into registers
+    constexpr int ITEMS = (HP * (CH / 4) + 255) / 256;
+    int goff[ITEMS], loff[ITEMS];
+    float4 pre[ITEMS];
+#pragma unroll
+    for (int q = 0; q < ITEMS; ++q) {
+        const int it = threadIdx.x + q * 256;
+        const int hp = it >> 2, seg = it & 3;
+        const int hy = hp / HW, hx = hp - hy * HW;
+        const int yy = ty0 + hy - 1, xx = tx0 + hx - 1;
+        const bool ok = it < HP * (CH / 4) && yy >= 0 && yy < r && xx >= 0 && xx < r;
+        goff[q] = ok ? yy * x_py + xx * C + seg * 4 : -1;
+        loff[q] = it < HP * (CH / 4) ? hp * PITCH + seg * 4 : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < ITEMS; ++q)
+        pre[q] = goff[q] >= 0 ? *reinterpret_cast<const float4*>(xb + goff[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int cc = 0; cc < C; cc += CH) {
         __syncthreads();
-        for (int it = threadIdx.x; it < HP * (CH / 4); it += 256) {
-            const int hp = it >> 2, seg = it & 3;
-            const int hy = hp / HW, hx = hp - hy * HW;
-            const int yy = ty0 + hy - 1, xx = tx0 + hx - 1;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (yy >= 0 && yy < r && xx >= 0 && xx < r) {
-                v = *reinterpret_cast<const float4*>(xb + (size_t)yy * x_py + (size_t)xx * C + cc + seg * 4);
-                v.x = v.x >= 0.f ? v.x : v.x * slope; v.y = v.y >= 0.f ? v.y : v.y * slope;
-                v.z = v.z >= 0.f ? v.z : v.z * slope; v.w = v.w >= 0.f ? v.w : v.w * slope;
-            }
-            *reinterpret_cast<float4*>(tile + hp * PITCH + seg * 4) = v;
+#pragma unroll
+        for (int q = 0; q < ITEMS; ++q) {
+            float4 v = pre[q];
+            v.x = v.x >= 0.f ? v.x : v.x * slope; v.y = v.y >= 0.f ? v.y : v.y * slope;
+            v.z = v.z >= 0.f ? v.z : v.z * slope; v.w = v.w >= 0.f ? v.w : v.w * slope;
+            if (loff[q] >= 0) *reinterpret_cast<float4*>(tile + loff[q]) = v;
         }
         __syncthreads();
+        if (cc + CH < C) {
+#pragma unroll
+            for (int q = 0; q < ITEMS; ++q)
+                pre[q] = goff[q] >= 0 ? *reinterpret_cast<const float4*>(xb + goff[q] + cc + CH) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         const float* wc = weff + cc;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
