@@ -1,0 +1,17 @@
+"""Diagnostic (not a pytest): run one long-K ping-pong conv with a -DSTAMPS build (MSR_LIB=...) that prints
+per-step segment durations of waves 0 (X) and 4 (Y) of one workgroup, in shader-clock cycles."""
+import sys
+import torch
+sys.path.insert(0, ".")
+from moonsuperresolution_amd import ops
+ctx = ops.OpContext()
+B, r, cin, N = 16, 32, 1024, 512
+x = torch.randn((B, r + 2, r + 2, cin), device="cuda")
+w = torch.randn((9, N, cin), device="cuda") * 0.01
+bias = torch.zeros(N, device="cuda")
+out = torch.empty((B, r, r, N), device="cuda")
+for _ in range(30):      # warm clocks
+    ops.conv3x3(ctx, x, w, bias, r, tile=4, out=out, precision="bf16x3")
+torch.cuda.synchronize()
+ops.conv3x3(ctx, x, w, bias, r, tile=5, out=out, precision="bf16x3")
+torch.cuda.synchronize()

@@ -98,7 +98,8 @@ def test_untileable_shape_is_rejected(ctx):
     (2, 16, 64, 128, 1, 0), (2, 16, 64, 128, 1, 1), (3, 8, 32, 64, 1, 1), (2, 16, 64, 128, 2, 1),
     (2, 8, 128, 128, 1, 1 + 256 * 4), (16, 1, 64, 64, 1, 1), (2, 16, 64, 128, 1, 3), (1, 32, 128, 256, 1, 3),
     (2, 16, 64, 128, 1, 4), (1, 32, 128, 256, 1, 4), (3, 16, 128, 256, 1, 4),
-    (2, 16, 64, 128, 1, 5), (1, 32, 128, 256, 1, 5), (3, 16, 128, 256, 1, 5)])
+    (2, 16, 64, 128, 1, 5), (1, 32, 128, 256, 1, 5), (3, 16, 128, 256, 1, 5),
+    (3, 128, 64, 256, 1, 5), (16, 64, 64, 256, 1, 5)])   # 384 / 512 tiles on 256 persistent workgroups: 1-2 tiles each
 def test_conv_bf16x3(ctx, B, r, cin, cout, stride, tile, frag):
     """3-term split-bf16 products, fp32 accumulation: error bound ~3*2^-18 per product -> rel L-inf <= 5e-5.
     Three kernels: LDS-staged weights (tiles 0/1), weights in VGPRs (| 0x40), LDS-staged input halo (tile 3 on the
