@@ -126,6 +126,18 @@ int msr_set_blend_window(msr_handle* h, const double* host_window, int32_t side)
  * weight reader (moonsuperresolution_amd/tf_checkpoint.py): checkpoint data and index blocks carry masked CRC-32C. */
 uint32_t msr_crc32c(const void* host_data, uint64_t n, uint32_t crc);
 
+/* ---- pre-processing resamplers ------------------------------------------------ */
+/* Replaces cv2.resize(dem, (0,0), fx=1/factor, fy=1/factor, interpolation=cv2.INTER_AREA) of preprocess
+ * (process_full_tiles.py:232,238) on a float32 raster [rows, cols] in device memory: dst [dst_rows, dst_cols] with
+ * dst_* = cvRound(src_* / factor); every destination pixel is the mean of its factor x factor block (NaN propagates;
+ * partial edge blocks average the pixels that exist). */
+int msr_resize_area(msr_handle* h, const float* src_dev, int32_t rows, int32_t cols, int32_t factor, float* dst_dev,
+                    int32_t dst_rows, int32_t dst_cols, void* stream);
+/* Replaces cv2.resize(dem_rs, dsize, interpolation=cv2.INTER_CUBIC) (process_full_tiles.py:241): Keys cubic,
+ * A = -0.75, pixel-centre mapping, replicated border, float32; dst [dst_rows, dst_cols]. */
+int msr_resize_cubic(msr_handle* h, const float* src_dev, int32_t rows, int32_t cols, float* dst_dev,
+                     int32_t dst_rows, int32_t dst_cols, void* stream);
+
 /* TIFF 6.0 LZW (compression 5) of HOST buffers, for the GeoTIFF reader / writer (moonsuperresolution_amd/geotiff.py;
  * the reference reads and writes LZW GeoTIFFs through GDAL: process_full_tiles.py:158-182, 481-531).
  * Both return the number of bytes produced, or -1 on a malformed stream / too small output buffer. */

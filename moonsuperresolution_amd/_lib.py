@@ -46,6 +46,8 @@ SYMBOLS = [
     ("msr_extract_patches", C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P, _P]),
     ("msr_stitch_tile", C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, _P, _P, _P]),
     ("msr_set_blend_window", C.c_int, [_P, _P, C.c_int32]),
+    ("msr_resize_area", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P]),
+    ("msr_resize_cubic", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P]),
     ("msr_crc32c", C.c_uint32, [_P, C.c_uint64, C.c_uint32]),
     ("msr_lzw_decode", C.c_int64, [_P, C.c_int64, _P, C.c_int64]),
     ("msr_lzw_encode", C.c_int64, [_P, C.c_int64, _P, C.c_int64]),

@@ -1243,6 +1243,26 @@ int msr_extract_patches(msr_handle* h, const float* img, const float* dem, int32
     return MSR_OK;
 }
 
+int msr_resize_area(msr_handle* h, const float* src, int32_t rows, int32_t cols, int32_t factor, float* dst,
+                    int32_t dst_rows, int32_t dst_cols, void* stream) {
+    if (!h) return MSR_ERR_INVALID;
+    if (!src || !dst || rows <= 0 || cols <= 0 || factor < 1 || dst_rows <= 0 || dst_cols <= 0)
+        return fail(h, MSR_ERR_INVALID, "msr_resize_area: bad argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, launch_resize_area(src, rows, cols, dst, dst_rows, dst_cols, factor, (hipStream_t)stream));
+    return MSR_OK;
+}
+
+int msr_resize_cubic(msr_handle* h, const float* src, int32_t rows, int32_t cols, float* dst, int32_t dst_rows,
+                     int32_t dst_cols, void* stream) {
+    if (!h) return MSR_ERR_INVALID;
+    if (!src || !dst || rows <= 0 || cols <= 0 || dst_rows <= 0 || dst_cols <= 0)
+        return fail(h, MSR_ERR_INVALID, "msr_resize_cubic: bad argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, launch_resize_cubic(src, rows, cols, dst, dst_rows, dst_cols, (hipStream_t)stream));
+    return MSR_OK;
+}
+
 int msr_set_blend_window(msr_handle* h, const double* host_window, int32_t side) {
     if (!h) return MSR_ERR_INVALID;
     const int ws = h->S - 2 * (h->S / 16);

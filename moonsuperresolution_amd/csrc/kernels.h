@@ -202,5 +202,7 @@ hipError_t launch_extract_patches(const float* img, const float* dem, int rows, 
 hipError_t launch_stitch_tile(const float* pred, const int* key, const float* dmm, int n, int S, int T, int stride,
                               float no_value, int as_implemented, const double* window, int* grid_ws,
                               float* mean, float* stdv, uint8_t* good, hipStream_t s);
+hipError_t launch_resize_area(const float* src, int h, int w, float* dst, int dh, int dw, int factor, hipStream_t s);
+hipError_t launch_resize_cubic(const float* src, int h, int w, float* dst, int dh, int dw, hipStream_t s);
 
 }  // namespace msr

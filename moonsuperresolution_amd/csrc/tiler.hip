@@ -185,4 +185,83 @@ hipError_t launch_stitch_tile(const float* pred, const int* key, const float* dm
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Raster resamplers of the reference's pre-processing (process_full_tiles.py:226-244: cv2.resize INTER_AREA x1/4,
+// twice, then INTER_CUBIC back to full size).  One thread per destination pixel, float32 operation order of
+// oracle/preprocess_ref.py (which restates OpenCV's published algorithm; this file is compiled with
+// -ffp-contract=off), so the two agree bit for bit.  HBM-bound: the full-resolution raster is read / written once.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) resize_area_kernel(const float* __restrict__ src, int h, int w,
+                                                          float* __restrict__ dst, int dh, int dw, int f) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)dh * dw) return;
+    const int dx = (int)(i % dw), dy = (int)(i / dw);
+    const int x0 = dx * f, y0 = dy * f;
+    if (y0 >= h || x0 >= w) { dst[i] = 0.f; return; }
+    if (y0 + f <= h && x0 + f <= w) {
+        // full block: rows outer, four columns at a time (sum += S[k] + S[k+1] + S[k+2] + S[k+3]), times 1/area
+        float sum = 0.f;
+        for (int r = 0; r < f; ++r) {
+            const float* S = src + (size_t)(y0 + r) * w + x0;
+            int k = 0;
+            for (; k + 4 <= f; k += 4) sum = sum + (((S[k] + S[k + 1]) + S[k + 2]) + S[k + 3]);
+            for (; k < f; ++k) sum = sum + S[k];
+        }
+        dst[i] = sum * (1.0f / (float)(f * f));
+    } else {
+        float sum = 0.f;
+        int n = 0;
+        for (int yy = y0; yy < min(y0 + f, h); ++yy)
+            for (int xx = x0; xx < min(x0 + f, w); ++xx) { sum = sum + src[(size_t)yy * w + xx]; ++n; }
+        dst[i] = sum / (float)n;
+    }
+}
+
+__device__ __forceinline__ void cubic_axis(int d, double scale, int n_src, int (&idx)[4], float (&c)[4]) {
+    const float f = (float)(((double)d + 0.5) * scale - 0.5);
+    const float fl = floorf(f);
+    const int s = (int)fl;
+    const float t = f - fl;
+    const float A = -0.75f;
+    c[0] = ((A * (t + 1.f) - 5.f * A) * (t + 1.f) + 8.f * A) * (t + 1.f) - 4.f * A;
+    c[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+    const float u = 1.f - t;
+    c[2] = ((A + 2.f) * u - (A + 3.f)) * u * u + 1.f;
+    c[3] = 1.f - c[0] - c[1] - c[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) idx[k] = min(max(s - 1 + k, 0), n_src - 1);
+}
+
+__global__ void __launch_bounds__(256) resize_cubic_kernel(const float* __restrict__ src, int h, int w,
+                                                           float* __restrict__ dst, int dh, int dw) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)dh * dw) return;
+    const int dx = (int)(i % dw), dy = (int)(i / dw);
+    int xi[4], yi[4];
+    float a[4], b[4];
+    cubic_axis(dx, (double)w / (double)dw, w, xi, a);
+    cubic_axis(dy, (double)h / (double)dh, h, yi, b);
+    float rows[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float* S = src + (size_t)yi[k] * w;
+        rows[k] = ((S[xi[0]] * a[0] + S[xi[1]] * a[1]) + S[xi[2]] * a[2]) + S[xi[3]] * a[3];   // horizontal pass
+    }
+    dst[i] = ((rows[0] * b[0] + rows[1] * b[1]) + rows[2] * b[2]) + rows[3] * b[3];            // vertical pass
+}
+
+hipError_t launch_resize_area(const float* src, int h, int w, float* dst, int dh, int dw, int factor, hipStream_t s) {
+    const long n = (long)dh * dw;
+    if (n <= 0 || factor < 1) return hipErrorInvalidValue;
+    resize_area_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(src, h, w, dst, dh, dw, factor);
+    return hipGetLastError();
+}
+
+hipError_t launch_resize_cubic(const float* src, int h, int w, float* dst, int dh, int dw, hipStream_t s) {
+    const long n = (long)dh * dw;
+    if (n <= 0 || h < 1 || w < 1) return hipErrorInvalidValue;
+    resize_cubic_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(src, h, w, dst, dh, dw);
+    return hipGetLastError();
+}
+
 }  // namespace msr

@@ -3,7 +3,7 @@
 Same names and argument meaning as the reference for the part of the class that is on the hot path
 (``DSRConfig``, ``padInputs``, ``generateTileList``, ``processTile``, ``rebuildTile``, ``rebuildMap``) and for the
 file boundary either side of it (``loadImages`` / ``saveGTiff`` on ``geotiff.py`` instead of GDAL).  Nodata
-in-filling and low-res-DEM synthesis (``preprocess``: OpenCV, SciPy) are not built — feed
+in-filling and low-res-DEM synthesis live in preprocess.py (``DEMSuperResolution.preprocess``) — or feed
 pre-processed rasters, as files (``processFiles``) or as arrays (``setImages`` / ``processMap``).
 
 What moves to the GPU (libmoonsr_hip.so, csrc/tiler.hip):
@@ -169,12 +169,27 @@ class DEMSuperResolution:
                               getattr(self, "geo_meta", None), nodata=self.no_value, dtype=out_type, compress="lzw",
                               predictor=2)
 
-    def processFiles(self) -> None:
-        """processMap of the reference on files (process_full_tiles.py:568-587): loadImages -> padInputs -> tiles ->
-        rebuildMap -> ``<map>_mean.tiff``, ``<map>_std.tiff``, ``<map>_good.tiff``.  The reference's ``preprocess``
-        (nodata in-filling and low-res-DEM synthesis with OpenCV / SciPy) is not part of this build: the DEM is used
-        as read, so feed the already pre-processed low-resolution DEM."""
+    def preprocess(self, swap_dsize: bool = True) -> None:
+        """process_full_tiles.py:226-244: in-fill the ortho (stored in ``self.image`` and, as in the reference, never
+        used afterwards), then replace ``self.dem`` by the synthesised low-resolution DEM (x1/4 area, in-fill, x1/4
+        area, cubic back to full size).  Resamplers on the GPU, in-filling with SciPy on the host (preprocess.py).
+
+        ``swap_dsize=True`` keeps the reference's (rows, cols)-as-(width, height) argument of :241, so a non-square
+        raster ends with a transposed-shape DEM and fails in padInputs exactly as the reference does; pass False to
+        resize to the raster's own shape."""
+        from . import preprocess as pp
+        if self.img is None or self.dem is None:
+            raise ValueError("preprocess needs the rasters: call loadImages() or setImages() first.")
+        self.image, self.dem = pp.preprocess(self._lib, self._h, self.device, self.img, self.dem, self.no_value,
+                                             swap_dsize=swap_dsize)
+
+    def processFiles(self, preprocess: bool = True) -> None:
+        """processMap of the reference on files (process_full_tiles.py:568-587): loadImages -> preprocess ->
+        padInputs -> tiles -> rebuildMap -> ``<map>_mean.tiff``, ``<map>_std.tiff``, ``<map>_good.tiff``.
+        ``preprocess=False`` skips the low-resolution-DEM synthesis (feed an already pre-processed DEM)."""
         self.loadImages()
+        if preprocess:
+            self.preprocess()
         mean, std, good = self.processMap()
         self.saveGTiff(mean, mean.dtype, "mean")
         self.saveGTiff(std, std.dtype, "std")
