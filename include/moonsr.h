@@ -152,7 +152,10 @@ typedef struct {
     double flops;         /* algorithmic FLOPs of those launches (2*MACs), 0 for memory-bound families */
     double bytes;         /* algorithmic bytes of those launches */
 } msr_kernel_stat;
-/* When on, every kernel launch of msr_forward is bracketed by hipEvents on the call's stream. */
+/* on = 1: every kernel launch of msr_forward is bracketed by hipEvents on the call's stream (an event costs the
+ * stream 2-3 us: ~7 % of a call's throughput).  on = 2: only the conv family is timed and a run of consecutive conv
+ * launches shares one pair of events (device_ms then includes the 1.5-3 us gaps inside a run; < 2 % overhead).
+ * on = 0: off. */
 int msr_profile_enable(msr_handle* h, int32_t on);
 int msr_profile_reset(msr_handle* h);
 /* Synchronises the recorded events and fills up to cap entries; *n = number of families. */

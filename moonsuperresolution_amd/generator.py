@@ -150,8 +150,9 @@ class Generator:
         _lib.raise_for(self._lib, self._h, self._lib.msr_device_bytes(self._h, C.byref(v)), "msr_device_bytes")
         return v.value
 
-    def profile(self, on: bool) -> None:
-        self._lib.msr_profile_enable(self._h, 1 if on else 0)
+    def profile(self, on) -> None:
+        """False / 0: off; True / 1: hipEvents around every launch; 2: around runs of conv launches only (cheap)."""
+        _lib.raise_for(self._lib, self._h, self._lib.msr_profile_enable(self._h, int(on)), "msr_profile_enable")
         self._lib.msr_profile_reset(self._h)
 
     def profile_read(self) -> Dict[str, dict]:
