@@ -740,7 +740,7 @@ int plan_spade(msr_handle* h) {
             p.out_split = h->prec == PREC_BF16X3;
             em.flops = 2.0 * B * r * r * 18.0 * 128;
             em.on_aux = true;
-            em.aux_group = i <= 3 ? 0 : i - 3;   // rb1-3 are tiny: one group
+            em.aux_group = i <= 4 ? 0 : 1;        // rb1-4 embeds are small and done early; rb5-6 carry the bytes
             if (hipEventCreateWithFlags(&em.done, hipEventDisableTiming) != hipSuccess)
                 return fail(h, MSR_ERR_DEVICE, "hipEventCreate failed");
             h->ops.push_back(em);
@@ -799,8 +799,8 @@ int plan_spade(msr_handle* h) {
     }
     // A cross-stream wait stalls the main stream for ~16 us whether or not the event has fired, so the aux stream
     // signals once per group (after the group's last mask-embedding conv; the stream is in order) and only the
-    // group's first consumer waits.
-    for (int grp = 0; grp < 4; ++grp) {
+    // group's first consumer waits: two groups, i.e. two waits per call.
+    for (int grp = 0; grp < 2; ++grp) {
         int last_aux = -1, first_wait = -1;
         for (size_t k = 0; k < h->ops.size(); ++k) {
             if (h->ops[k].aux_group != grp) continue;

@@ -9,7 +9,7 @@ for i in $(seq 1 $R); do
     python - <<PY
 import json
 d=json.loads(open("gpurun_out/ab_$v$i.log").read().strip().splitlines()[-1])
-print("$v$i", round(d["value"],1), round(d["ms_per_step"],3), round(d["kernel_ms_per_call"].get("conv_igemm_bf16x3",0),3), flush=True)
+print("$v$i", round(d["value"],1), round(d["ms_per_step"],3), round(d.get("kernel_ms_per_call",{}).get("conv_igemm_bf16x3",0),3), flush=True)
 PY
   done
 done
