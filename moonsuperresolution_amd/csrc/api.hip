@@ -571,7 +571,8 @@ ConvVariant pick_conv_variant(int B, int rout, int N, int stride, int epi, int p
     v.wt_frag = 0;
     if (prec == PREC_BF16X3) {
         if (v.tile == TILE_64x64) v.wt_frag = 1;                          // B in VGPRs: +18 % on the small tile
-        else if (stride == 1 && rout >= 16 && cin % 64 == 0) {
+        else if (stride == 1 && rout >= 16 && cin % 64 == 0 &&
+                 (size_t)B * (rout + 2) * (rout + 2) * cin * sizeof(float) < ((size_t)1 << 31)) {   // raw buffer loads: 2 GiB
             // LDS-staged input halo.  The 512-thread ping-pong form (one workgroup per CU, 16 x 16 pixels) is
             // 10-25 % faster as soon as it fills the chip once; below that, two 256-thread workgroups per CU.
             const long pp_blocks = (long)B * (rout / 16) * (rout / 16) * (N / 128);

@@ -1611,6 +1611,7 @@ static hipError_t launch_halo(const ConvParams& p, int epi, int sh, hipStream_t 
     if (g.tb != 1 || g.th_l != 3 || g.tw_l != 4 || p.stride != 1 || p.KH != 3 || p.KW != 3 || p.ksplit > 1 ||
         p.Cin % 64)   // the K loop is unrolled by two steps: 9 * (Cin / 32) must be even
         return hipErrorInvalidValue;
+    if ((size_t)p.B * p.in_pb * sizeof(float) >= ((size_t)1 << 31)) return hipErrorInvalidValue;   // buffer descriptor range
     if (sh) {
         switch (epi) {
             case EPI_BIAS: conv_igemm_bf16x3_halo<EPI_BIAS, 1><<<g.tiles_mn, 256, HALO16_LDS, s>>>(p, g); break;
@@ -1635,6 +1636,7 @@ static hipError_t launch_pp(const ConvParams& p, int epi, hipStream_t s) {
     if (g.tb != 1 || g.th_l != 4 || g.tw_l != 4 || p.stride != 1 || p.KH != 3 || p.KW != 3 || p.ksplit > 1 ||
         p.Cin % 64)
         return hipErrorInvalidValue;
+    if ((size_t)p.B * p.in_pb * sizeof(float) >= ((size_t)1 << 31)) return hipErrorInvalidValue;   // buffer descriptor range
     // persistent: one workgroup per CU (144 KB of LDS each), a multiple of 8 so that every XCD gets the same count
     static int n_cu = 0;
     if (!n_cu) {
