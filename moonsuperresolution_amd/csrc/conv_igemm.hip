@@ -1147,19 +1147,30 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
     float4 xpre[4][2], cpre[8];                   // the epilogue's memory operands, requested on step 16 of the last pair
 #define MSR_BUFLD(rs, voff, soff) \
     __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (int)(soff), 0))
-#define MSR_LOAD_H(soff)                                                                         \
+#define MSR_LOAD_H_LO(soff)                                                                      \
     {                                                                                            \
         rh0 = MSR_BUFLD(rs_in, h_goff[0], soff); rh1 = MSR_BUFLD(rs_in, h_goff[1], soff);        \
-        rh2 = MSR_BUFLD(rs_in, h_goff[2], soff); rh3 = MSR_BUFLD(rs_in, h_goff[3], soff);        \
-        rh4 = MSR_BUFLD(rs_in, h_goff[4], soff); rh5 = MSR_BUFLD(rs_in, h_goff[5], soff);        \
+        rh2 = MSR_BUFLD(rs_in, h_goff[2], soff);                                                 \
     }
-#define MSR_WRITE_H(buf)                                                                         \
+#define MSR_LOAD_H_HI(soff)                                                                      \
+    {                                                                                            \
+        rh3 = MSR_BUFLD(rs_in, h_goff[3], soff); rh4 = MSR_BUFLD(rs_in, h_goff[4], soff);        \
+        rh5 = MSR_BUFLD(rs_in, h_goff[5], soff);                                                 \
+    }
+#define MSR_LOAD_H(soff) { MSR_LOAD_H_LO(soff) MSR_LOAD_H_HI(soff) }
+#define MSR_WRITE_H_LO(buf)                                                                      \
     {                                                                                            \
         float* h_ = Ah + (buf) * HP * BKP;                                                       \
         *reinterpret_cast<float4*>(h_ + h_loff[0]) = rh0; *reinterpret_cast<float4*>(h_ + h_loff[1]) = rh1; \
-        *reinterpret_cast<float4*>(h_ + h_loff[2]) = rh2; *reinterpret_cast<float4*>(h_ + h_loff[3]) = rh3; \
-        *reinterpret_cast<float4*>(h_ + h_loff[4]) = rh4; *reinterpret_cast<float4*>(h_ + h_loff[5]) = rh5; \
+        *reinterpret_cast<float4*>(h_ + h_loff[2]) = rh2;                                        \
     }
+#define MSR_WRITE_H_HI(buf)                                                                      \
+    {                                                                                            \
+        float* h_ = Ah + (buf) * HP * BKP;                                                       \
+        *reinterpret_cast<float4*>(h_ + h_loff[3]) = rh3; *reinterpret_cast<float4*>(h_ + h_loff[4]) = rh4; \
+        *reinterpret_cast<float4*>(h_ + h_loff[5]) = rh5;                                        \
+    }
+#define MSR_WRITE_H(buf) { MSR_WRITE_H_LO(buf) MSR_WRITE_H_HI(buf) }
 // weights of K-step U of a chunk pair, relative to the pair's first chunk
 #define MSR_WOFF(U) (((U) / 9) * (BKC * 4) + (unsigned)((U) % 9) * w_tap_bytes)
 #define MSR_LOAD_B(soff)                                                                         \
@@ -1182,7 +1193,10 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
             if ((LASTP) && (T) >= 9) MSR_LOAD_H(h_next)                                          \
             else MSR_LOAD_H(h_tile + h_pair + ((T) / 9 + 1) * BKC * 4);                          \
         }                                                                                        \
-        if ((T) % 9 == 7) MSR_WRITE_H((((T) / 9) & 1) ^ 1);                                      \
+        /* the halo of the next chunk goes to LDS in two halves (taps 6 and 7): all six stores in one R make that   \
+           segment longer than the partner's matrix segment (1060 vs 840 cycles) */              \
+        if ((T) % 9 == 6) MSR_WRITE_H_LO((((T) / 9) & 1) ^ 1);                                   \
+        if ((T) % 9 == 7) MSR_WRITE_H_HI((((T) / 9) & 1) ^ 1);                                   \
         const float* a_ = Ah + (((T) / 9) & 1) * HP * BKP + ((((T) % 9) / 3) * HW + (((T) % 9) % 3)) * BKP; \
         const float* b_ = Bs + ((T) & 1) * BN * BKP;                                             \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
@@ -1265,6 +1279,10 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
 #undef MSR_BUFLD
 #undef MSR_LOAD_H
 #undef MSR_WRITE_H
+#undef MSR_WRITE_H_LO
+#undef MSR_WRITE_H_HI
+#undef MSR_LOAD_H_LO
+#undef MSR_LOAD_H_HI
 #undef MSR_WOFF
 #undef MSR_LOAD_B
 #undef MSR_WRITE_B
