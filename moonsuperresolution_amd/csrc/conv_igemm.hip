@@ -1218,14 +1218,26 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0); \
         }                                                                                        \
     }
+// Diagnostic build only (-DMSR_PP_STAMPS, tests/gpu_pp_stamps.py): s_memtime stamps of waves 0 (X) and 4 (Y) of one
+// workgroup around the segments of one chunk pair, kept in the LDS words behind the product's 144,640 bytes.
+#ifdef MSR_PP_STAMPS
+#define MSR_STAMP()                                                                              \
+    if (dbg_on && lane == 0 && (wave & 3) == 0) dbg[(wave >> 2) * 1024 + dbg_n++] = (unsigned)__builtin_amdgcn_s_memtime();
+#else
+#define MSR_STAMP()
+#endif
 #define MSR_STEP(T, LASTP)                                                                       \
     {                                                                                            \
+        MSR_STAMP()                                                                              \
         MSR_R(T, LASTP)                                                                          \
         if ((LASTP) && (T) == 16) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0); \
+        MSR_STAMP()                                                                              \
         __syncthreads();                                                                         \
+        MSR_STAMP()                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         MSR_M()                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                       \
+        MSR_STAMP()                                                                              \
         /* Y's M on the workgroup's very last step has no partner segment */                     \
         if (!((LASTP) && (T) == 17) || has_next || grp == 0) __syncthreads();                    \
     }
@@ -1235,6 +1247,11 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
     MSR_STEP(10, LASTP) MSR_STEP(11, LASTP) MSR_STEP(12, LASTP) MSR_STEP(13, LASTP)              \
     MSR_STEP(14, LASTP) MSR_STEP(15, LASTP) MSR_STEP(16, LASTP) MSR_STEP(17, LASTP)
 
+#ifdef MSR_PP_STAMPS
+    unsigned* dbg = reinterpret_cast<unsigned*>(smem + (2 * HP + 2 * BN) * BKP);
+    int dbg_n = 0;
+    bool dbg_on = false;
+#endif
     // prologue of the workgroup's first tile: halo of chunk 0 and the weights of step 0 into LDS, the weights of
     // step 1 stay in flight
     MSR_LOAD_H(h_tile);
@@ -1261,7 +1278,13 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
         h_pair = 0;
         w_pair = 0;
         for (int pr = 0; pr < chunks / 2 - 1; ++pr) {
+#ifdef MSR_PP_STAMPS
+            dbg_on = blockIdx.x == 8 && pr == 2 && dbg_n == 0;
+#endif
             MSR_PAIR(false)
+#ifdef MSR_PP_STAMPS
+            dbg_on = false;
+#endif
             h_pair += 2 * BKC * 4;
             w_pair += 2 * BKC * 4;
         }
@@ -1275,6 +1298,15 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
         h_tile = h_next;
         w_tile = w_next;
     }
+#ifdef MSR_PP_STAMPS
+    if (blockIdx.x == 8 && lane == 0 && (wave & 3) == 0) {
+        const unsigned* d = dbg + (wave >> 2) * 1024;
+        for (int k = 0; k + 3 < dbg_n; k += 4)
+            printf("wave %d step %2d: R %4u  barrier %4u  M %4u  barrier+next %4u cycles\n", wave, k / 4, d[k + 1] - d[k],
+                   d[k + 2] - d[k + 1], d[k + 3] - d[k + 2], k + 4 < dbg_n ? d[k + 4] - d[k + 3] : 0u);
+    }
+#endif
+#undef MSR_STAMP
 #undef MSR_DECODE
 #undef MSR_BUFLD
 #undef MSR_LOAD_H
@@ -1408,7 +1440,11 @@ static hipError_t set_attr_bf16x3() {
 static constexpr size_t HALO_LDS = (size_t)(180 + 2 * 128) * 36 * sizeof(float);
 static constexpr size_t HALO16_LDS = (size_t)(180 + 2 * 128) * 40 * sizeof(float);
 
+#ifdef MSR_PP_STAMPS
+static constexpr size_t PP_LDS = (size_t)(2 * 324 + 2 * 128) * 40 * sizeof(float) + 8192;   // + the stamp words
+#else
 static constexpr size_t PP_LDS = (size_t)(2 * 324 + 2 * 128) * 40 * sizeof(float);
+#endif
 
 static hipError_t set_attr_halo() {
     hipError_t e;

@@ -1,5 +1,10 @@
-"""Diagnostic (not a pytest): run one long-K ping-pong conv with a -DSTAMPS build (MSR_LIB=...) that prints
-per-step segment durations of waves 0 (X) and 4 (Y) of one workgroup, in shader-clock cycles."""
+"""Diagnostic (not a pytest): run one long-K ping-pong conv with a stamped build of the library, which prints the
+per-step segment durations (R, barrier, M, barrier) of waves 0 (X) and 4 (Y) of one workgroup in shader-clock cycles.
+
+    cp -r moonsuperresolution_amd/csrc /tmp/csrc_stamps && cp -r include /tmp/include   # keeps the product objects clean
+    make -C /tmp/csrc_stamps clean all EXTRA=-DMSR_PP_STAMPS        # (the Makefile reads ../../include: copy the tree)
+    MSR_LIB=/path/to/stamped/libmoonsr_hip.so python tests/gpu_pp_stamps.py
+"""
 import sys
 import torch
 sys.path.insert(0, ".")
