@@ -160,6 +160,11 @@ int msr_profile_enable(msr_handle* h, int32_t on);
 int msr_profile_reset(msr_handle* h);
 /* Synchronises the recorded events and fills up to cap entries; *n = number of families. */
 int msr_profile_read(msr_handle* h, msr_kernel_stat* out, int32_t cap, int32_t* n);
+/* The recorded intervals of one family (0 = the conv family), in ms relative to ref_event (a hipEvent_t the caller
+ * recorded before the calls): lets a caller that drives several handles on several streams take the UNION of the
+ * family's busy intervals instead of their sum. */
+int msr_profile_runs(msr_handle* h, void* ref_event, int32_t family, double* start_ms, double* end_ms, double* flops,
+                     int64_t* launches, int32_t cap, int32_t* n);
 /* Algorithmic FLOPs of one msr_forward call (all patches), the figure BASELINE.md section 2 derives. */
 int msr_forward_flops(const msr_handle* h, double* flops);
 /* Kernel-level entry (parity tests and micro-benchmarks of the dominant kernel): one conv_igemm_f32 launch.

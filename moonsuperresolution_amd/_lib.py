@@ -54,6 +54,7 @@ SYMBOLS = [
     ("msr_profile_enable", C.c_int, [_P, C.c_int32]),
     ("msr_profile_reset", C.c_int, [_P]),
     ("msr_profile_read", C.c_int, [_P, C.POINTER(MsrKernelStat), C.c_int32, C.POINTER(C.c_int32)]),
+    ("msr_profile_runs", C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, C.c_int32, _P]),
     ("msr_forward_flops", C.c_int, [_P, C.POINTER(C.c_double)]),
     ("msr_op_conv3x3", C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                  _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P]),

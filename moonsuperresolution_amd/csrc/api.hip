@@ -1240,6 +1240,25 @@ int msr_profile_read(msr_handle* h, msr_kernel_stat* out, int32_t cap, int32_t* 
     return MSR_OK;
 }
 
+int msr_profile_runs(msr_handle* h, void* ref_event, int32_t family, double* start_ms, double* end_ms, double* flops,
+                     int64_t* launches, int32_t cap, int32_t* n) {
+    if (!h || !ref_event || !start_ms || !end_ms || !flops || !launches || !n || family < 0 || family >= FAM_COUNT)
+        return MSR_ERR_INVALID;
+    HIPCHK(h, hipDeviceSynchronize());
+    int k = 0;
+    for (auto& r : h->prof) {
+        if (r.fam != family) continue;
+        if (k >= cap) return fail(h, MSR_ERR_INVALID, "msr_profile_runs: %d records do not fit", (int)h->prof.size());
+        float a = 0.f, b = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&a, (hipEvent_t)ref_event, r.a));
+        HIPCHK(h, hipEventElapsedTime(&b, (hipEvent_t)ref_event, r.b));
+        start_ms[k] = a; end_ms[k] = b; flops[k] = r.flops; launches[k] = r.launches;
+        ++k;
+    }
+    *n = k;
+    return MSR_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // tiler / stitcher
 // ------------------------------------------------------------------------------------------------

@@ -67,9 +67,16 @@ class Generator:
             if e.shape != (batch_size, latent_dim):
                 raise ValueError(f"eps must be [{batch_size}, {latent_dim}], got {e.shape}")
             self._eps_fixed = torch.from_numpy(e).to(self.device)
+        self._ctor = dict(image_size=image_size, batch_size=batch_size, latent_dim=latent_dim, variant=variant,
+                          weights=weights, eps=eps, device=device, precision=precision)
         if isinstance(weights, (int, np.integer)):
             weights = make_weights(variant, image_size, latent_dim, seed=int(weights))
         self.load(weights)
+
+    def clone(self) -> "Generator":
+        """A second handle with the same weights (its own workspace), for issuing independent calls on another
+        stream: the latency-bound head of one call then overlaps the matrix-bound tail of the other."""
+        return Generator(**self._ctor)
 
     # -- weights -----------------------------------------------------------------------------------
     def load(self, weights: Mapping[str, np.ndarray]) -> None:
@@ -161,6 +168,17 @@ class Generator:
         _lib.raise_for(self._lib, self._h, self._lib.msr_profile_read(self._h, arr, 16, C.byref(n)), "msr_profile_read")
         return {arr[i].name.decode(): dict(launches=arr[i].launches, device_ms=arr[i].device_ms, flops=arr[i].flops,
                                            bytes=arr[i].bytes) for i in range(n.value)}
+
+    def profile_runs(self, ref_event: torch.cuda.Event, family: int = 0):
+        """[(start_ms, end_ms, flops, launches)] of the recorded intervals of one kernel family (0 = conv) relative to
+        ``ref_event`` (recorded by the caller before the calls)."""
+        cap = 1 << 16
+        a, b, f = (C.c_double * cap)(), (C.c_double * cap)(), (C.c_double * cap)()
+        l = (C.c_int64 * cap)()
+        n = C.c_int32()
+        rc = self._lib.msr_profile_runs(self._h, C.c_void_p(ref_event.cuda_event), family, a, b, f, l, cap, C.byref(n))
+        _lib.raise_for(self._lib, self._h, rc, "msr_profile_runs")
+        return [(a[i], b[i], f[i], l[i]) for i in range(n.value)]
 
     def close(self) -> None:
         if getattr(self, "_h", None):

@@ -74,7 +74,7 @@ class DEMSuperResolution:
     """
 
     def __init__(self, config: DSRConfig, model: Callable = lambda x, training=False: x, device: int = 0,
-                 as_implemented: bool = True) -> None:
+                 as_implemented: bool = True, pipeline: int = 2) -> None:
         self.map_name = config.map_name
         self.save_path = config.save_path
         self.folder_path = config.source_folder_path
@@ -88,6 +88,9 @@ class DEMSuperResolution:
         self.tile_size = int(config.tile_size)
         self.model = model
         self.as_implemented = as_implemented
+        self.pipeline = max(1, int(pipeline))        # generator handles / streams the calls of a tile alternate over
+        self._gens = None
+        self._pstreams = None
         S, s = self.image_size, self.stride
         if S < 64 or S & (S - 1):
             raise ValueError("image_size must be a power of two >= 64")
@@ -104,6 +107,7 @@ class DEMSuperResolution:
                 raise ValueError("Generator image_size/batch_size differ from the DSRConfig")
             self._h = self._gen._h
             self._own_handle = False
+            self._make_pipeline()
         else:
             # a handle only for the tiler kernels (no weights needed); variant is irrelevant
             cfg = _lib.MsrConfig(S, max(1, min(self.batch_size, 16)), 256, _lib.VARIANT_IDS["gaugan_no_kl"], device, 0)
@@ -222,6 +226,13 @@ class DEMSuperResolution:
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def _make_pipeline(self) -> None:
+        """`pipeline` generator handles with the same weights, each with its own stream (built once, at construction
+        when the model is a Generator)."""
+        self._gens = [self._gen] + [self._gen.clone() for _ in range(self.pipeline - 1)]
+        with torch.cuda.device(self.device):
+            self._pstreams = [torch.cuda.Stream(self.device) for _ in self._gens]
+
     def patchOrigins(self, px: int, py: int) -> np.ndarray:
         """[n, 2] int32 (xx, yy) in padded coordinates, generation order (process_full_tiles.py:453-454)."""
         span = self.tile_size + self.image_size - self.stride
@@ -265,16 +276,35 @@ class DEMSuperResolution:
             sx = torch.from_numpy(np.ascontiguousarray(sel[:, 0])).to(dev)
             sy = torch.from_numpy(np.ascontiguousarray(sel[:, 1])).to(dev)
             preds = torch.empty((max(total, 1), S, S), dtype=torch.float32, device=dev)
-            batch = torch.empty((B, S, S, 2), dtype=torch.float32, device=dev)
-            for c in range(ncall):
-                rc = lib.msr_extract_patches(h, self.img_padded.data_ptr(), self.dem_padded.data_ptr(), rows, cols,
-                                             sx[c * B:].data_ptr(), sy[c * B:].data_ptr(), mm_sel[c * B:].data_ptr(),
-                                             B, batch.data_ptr(), self._stream())
-                _lib.raise_for(lib, h, rc, "msr_extract_patches")
-                if self._gen is not None:
-                    out = self._gen.forward_device(batch)                       # [B,S,S,1], stays in HBM
-                    preds[c * B:(c + 1) * B] = out[..., -1]
-                else:
+            if self._gen is not None:
+                # The calls of a tile are independent batches: alternate them over `pipeline` generator handles, each
+                # on its own stream, so that the low-occupancy head of one call overlaps the tail of the other.
+                # Patches go from the rasters to `preds` without leaving HBM.
+                if self._gens is None:
+                    self._make_pipeline()
+                cur = torch.cuda.current_stream(dev)
+                batches = [torch.empty((B, S, S, 2), dtype=torch.float32, device=dev) for _ in self._gens]
+                for st in self._pstreams:
+                    st.wait_stream(cur)
+                for c in range(ncall):
+                    k = c % len(self._gens)
+                    with torch.cuda.stream(self._pstreams[k]):
+                        rc = lib.msr_extract_patches(h, self.img_padded.data_ptr(), self.dem_padded.data_ptr(), rows,
+                                                     cols, sx[c * B:].data_ptr(), sy[c * B:].data_ptr(),
+                                                     mm_sel[c * B:].data_ptr(), B, batches[k].data_ptr(), self._stream())
+                        _lib.raise_for(lib, h, rc, "msr_extract_patches")
+                        self._gens[k].forward_device(batches[k], out=preds[c * B:(c + 1) * B].unsqueeze(-1))
+                for st in self._pstreams:
+                    cur.wait_stream(st)
+                    for t in batches + [preds, sx, sy, mm_sel]:
+                        t.record_stream(st)
+            else:
+                batch = torch.empty((B, S, S, 2), dtype=torch.float32, device=dev)
+                for c in range(ncall):
+                    rc = lib.msr_extract_patches(h, self.img_padded.data_ptr(), self.dem_padded.data_ptr(), rows, cols,
+                                                 sx[c * B:].data_ptr(), sy[c * B:].data_ptr(), mm_sel[c * B:].data_ptr(),
+                                                 B, batch.data_ptr(), self._stream())
+                    _lib.raise_for(lib, h, rc, "msr_extract_patches")
                     out = np.array(self.model(batch.cpu().numpy(), training=False))[:, :, :, -1]
                     preds[c * B:(c + 1) * B] = torch.from_numpy(np.ascontiguousarray(out, dtype=np.float32)).to(dev)
             key_d = torch.from_numpy(np.ascontiguousarray(keys[:nv])).to(dev) if nv else torch.zeros((1, 2), dtype=torch.int32, device=dev)
@@ -327,6 +357,9 @@ class DEMSuperResolution:
         return self.rebuildMap(self.processTiles(self.generateTileList()))
 
     def close(self) -> None:
+        for g in (getattr(self, "_gens", None) or [])[1:]:
+            g.close()
+        self._gens = None
         if getattr(self, "_own_handle", False) and self._h:
             self._lib.msr_destroy(self._h)
             self._h = None
