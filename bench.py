@@ -14,11 +14,12 @@ over one batch of synthetic (ortho, low-res DEM) patches that is already residen
 Metric: 512x512 DEM tiles/s over the whole job (a 512x512 tile = four 256x256 patches).
 N > 1: one process per GPU (torch.distributed / RCCL only for the timing barrier + max); patches are
 independent units, so ranks share nothing on the data path ("weak" scaling: per-GPU work is fixed).
-Consecutive steps are independent batches, so they are issued alternately on --streams (default 2) generator handles,
-each on its own HIP stream: the latency-bound head of one call (encoder, dense, the r <= 8 layers: ~20 % of a call at
-low occupancy) overlaps the matrix-bound tail of the other (+4-5 % throughput; the driver's tile loop does the same).
-`value` is that pipelined throughput; `p50_ms_per_call` / `p50_latency_ms_per_tile` come from a separate
-single-stream pass after the timed region (a call's latency with nothing else in flight).
+--streams 2 issues consecutive steps (independent batches) alternately on two generator handles, each on its own HIP
+stream: the latency-bound head of one call (encoder, dense, the r <= 8 layers: ~20 % of a call at low occupancy) then
+overlaps the matrix-bound tail of the other (+5-7 % throughput; the driver's tile loop, tiler.py, does this by
+default).  The default is ONE stream, so that the per-launch durations bench.py reports and a rocprofv3 kernel trace
+of the same command agree (overlapping kernels of two streams stretch each other's traced durations).
+`p50_ms_per_call` / `p50_latency_ms_per_tile` come from a single-stream pass after the timed region.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -103,7 +104,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="spade256")
     ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="bf16x3",
                     help="conv arithmetic: exact fp32 MFMA, or 3-term split-bf16 on the bf16 MFMA (fp32 accumulate)")
-    ap.add_argument("--streams", type=int, default=2, help="generator handles / HIP streams the steps alternate over")
+    ap.add_argument("--streams", type=int, default=1, help="generator handles / HIP streams the steps alternate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     args = ap.parse_args()

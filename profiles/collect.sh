@@ -28,6 +28,7 @@ echo "pmc sq done"
 rocprofv3 --kernel-trace --stats -d $O/kt_bench -o kt --output-format csv -- python3 bench.py --no-cpu-baseline > $O/kt_bench.log 2>&1 || exit 1
 echo "trace of bench.py done"
 python bench.py > $O/bench_spade256_bf16x3.json 2> $O/bench_spade256_bf16x3.err || exit 1
+python bench.py --streams 2 --no-cpu-baseline > $O/bench_spade256_bf16x3_2streams.json 2> /dev/null || exit 1
 python bench.py --workload spade512 > $O/bench_spade512_bf16x3.json 2> $O/bench_spade512_bf16x3.err || exit 1
 python bench.py --precision fp32 --steps 20 > $O/bench_spade256_fp32.json 2> $O/bench_spade256_fp32.err || exit 1
 echo "bench done"
