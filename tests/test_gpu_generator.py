@@ -41,6 +41,39 @@ def test_spade64_matches_golden_and_blocks(Generator, variant):
     gen.close()
 
 
+def test_profile_modes_and_clone(Generator):
+    """msr_profile_enable: mode 1 brackets every launch, mode 2 only runs of conv launches (bench.py's timed region);
+    both count the same conv launches and FLOPs, and msr_profile_runs returns ordered intervals.  A clone is a second
+    handle with the same weights: bit-identical output."""
+    w = make_weights("gaugan", 64, seed=1234, bias_scale=0.05)
+    eps = make_latent_noise(2, 256, 7)
+    gen = Generator(64, 2, variant="gaugan", weights=w, eps=eps)
+    x = torch.from_numpy(synthetic_patches(2, 64, 0)).cuda()
+    y0 = gen.forward_device(x).cpu().numpy()
+    stats = {}
+    for mode in (1, 2):
+        gen.profile(mode)
+        ref = torch.cuda.Event(enable_timing=True)
+        ref.record()
+        for _ in range(3):
+            gen.forward_device(x)
+        stats[mode] = gen.profile_read()
+        runs = gen.profile_runs(ref)
+        gen.profile(0)
+        conv = stats[mode]["conv_igemm_bf16x3"]
+        assert sum(r[3] for r in runs) == conv["launches"] and abs(sum(r[2] for r in runs) - conv["flops"]) < 1e-3 * conv["flops"]
+        assert all(0 <= a <= b for a, b, _, _ in runs)
+    assert stats[1]["conv_igemm_bf16x3"]["launches"] == stats[2]["conv_igemm_bf16x3"]["launches"] == 3 * 34
+    assert stats[1]["conv_igemm_bf16x3"]["flops"] == stats[2]["conv_igemm_bf16x3"]["flops"]
+    assert set(stats[2]) == {"conv_igemm_bf16x3"} and len(stats[1]) > 4
+    with pytest.raises(ValueError):
+        gen.profile(3)
+    twin = gen.clone()
+    assert np.array_equal(twin.forward_device(x).cpu().numpy(), y0)
+    twin.close()
+    gen.close()
+
+
 def test_cnn_variant_equals_no_kl(Generator):
     w = make_weights("cnn", 64, seed=1234, bias_scale=0.05)
     x = synthetic_patches(2, 64, 0)

@@ -132,6 +132,13 @@ def test_generator_through_tiler_vs_oracle(dsr):
     span = float(dem.max() - dem.min())
     assert np.abs(mean[ok] - rm[ok]).max() <= 1e-3 * span
     assert np.abs(std[ok] - rs[ok]).max() <= 1e-3 * span
+    # the tile loop alternates its calls over two generator handles (pipeline=2, the default); one handle on one
+    # stream must give exactly the same rasters (the kernels are deterministic, the clone has the same weights)
+    d1 = DEMSuperResolution(cfg, model=gen, pipeline=1)
+    m1, s1, g1 = d1.processMap(img, dem)
+    assert np.array_equal(m1, mean) and np.array_equal(s1, std) and np.array_equal(g1, good)
+    assert len(d._gens) == 2 and len(d1._gens) == 1
+    d1.close()
     d.close()
     gen.close()
 
