@@ -253,6 +253,11 @@ def main():
             if args.precision == "bf16x3":
                 res["roofline"]["mfma_executed_tflops"] = 3 * ach   # three bf16 MFMA products per algorithmic one
                 res["roofline"]["frac_of_executed_mfma_peak"] = 3 * ach / peak
+                res["roofline"]["note"] = ("frac = algorithmic FLOP/s over the dense bf16 MFMA peak; bf16x3 issues three bf16 "
+                                           "MFMA products per algorithmic product, so the matrix pipe executes 3x `achieved` "
+                                           "(frac_of_executed_mfma_peak); SQ_VALU_MFMA_BUSY_CYCLES of the dominant kernel: "
+                                           "profiles/r01_spade256_bf16x3_sq_counters.txt (80 % long-K, 70 % gamma/beta layers "
+                                           "at the ~1.94 GHz the chip holds under this load)")
             pmc = pmc_traffic(args.workload + ("" if args.precision == "fp32" else "_bf16x3"))
             if pmc and "conv_igemm" in pmc[0]:
                 res["roofline"]["traffic"] = pmc[0]["conv_igemm"]["hbm_bytes_per_forward"] / (conv["launches"] / args.steps)
