@@ -55,47 +55,41 @@ def resize_cubic(lib, handle, src: torch.Tensor, dsize_wh: Tuple[int, int]) -> t
 
 
 def interpolateMissingValues(data: np.ndarray, no_value: float, max_fill_area: int = 256) -> np.ndarray:
-    """process_full_tiles.py:184-212.  Cubic ``griddata`` over the valid pixels of the tile; only connected regions
-    smaller than ``max_fill_area`` take the interpolated values.  Like the reference, ``np.unique`` counts the
-    background label (the valid pixels) together with the holes."""
+    """process_full_tiles.py:184-212 (in place; also returned).  A cubic ``griddata`` surface through the valid pixels of
+    the tile; only 8-connected hole regions smaller than ``max_fill_area`` take its values.  Like the reference, the
+    region census includes label 0 — the VALID pixels — so it takes part in the "smallest region too large" test and
+    in the size filter."""
     from scipy import interpolate, ndimage
-    x = np.arange(0, data.shape[1])
-    y = np.arange(0, data.shape[0])
-    invalid_mask = data <= no_value
-    if not np.any(invalid_mask):          # no missing values
+    holes = data <= no_value
+    if not holes.any() or holes.all():          # nothing to fill / nothing to interpolate from
         return data
-    if not np.any(~invalid_mask):         # all the values are missing
+    labels, _ = ndimage.label(holes, structure=np.ones((3, 3), dtype=bool))
+    sizes = np.bincount(labels.ravel())         # sizes[0] = number of valid pixels, sizes[k] = pixels of hole k
+    if sizes.min() > max_fill_area:             # every region (the valid area included) is too large
         return data
-    labels, _ = ndimage.label(invalid_mask, structure=np.ones((3, 3), dtype=bool))
-    ids, counts = np.unique(labels, return_counts=True)
-    if np.min(counts) > max_fill_area:    # missing areas are too large to be interpolated
-        return data
-    xx, yy = np.meshgrid(x, y)
-    x1 = xx[~invalid_mask]
-    y1 = yy[~invalid_mask]
-    known_values = data[~invalid_mask]
-    interp_image = interpolate.griddata((x1, y1), known_values.ravel(), (xx, yy), method="cubic")
-    to_keep_mask = np.zeros_like(data, dtype=bool)
-    for id_, count in zip(ids, counts):
-        if count < max_fill_area:
-            to_keep_mask[labels == id_] = True
-    data[to_keep_mask] = interp_image[to_keep_mask]
+    rows, cols = np.nonzero(~holes)             # row-major, the order of the reference's boolean indexing
+    grid_r, grid_c = np.mgrid[0:data.shape[0], 0:data.shape[1]]
+    surface = interpolate.griddata((cols, rows), data[rows, cols], (grid_c, grid_r), method="cubic")
+    take = (sizes < max_fill_area)[labels]
+    data[take] = surface[take]
     return data
 
 
 def fillNan(image: np.ndarray, no_value: float, tile_size: int = 1024, border: int = 128,
             max_fill_area: int = 256) -> np.ndarray:
-    """process_full_tiles.py:214-224: overlapping tiles of ``tile_size``; only each tile's interior is written."""
-    new_image = image.copy()
-    stride = tile_size - border * 2
-    for y in range(0, image.shape[0], stride):
-        ymax = min(y + tile_size - border, image.shape[0] - border)
-        for x in range(0, image.shape[1], stride):
-            tmp = image[y:y + tile_size, x:x + tile_size]
-            xmax = min(x + tile_size - border, image.shape[1] - border)
-            filled = interpolateMissingValues(tmp.copy(), no_value, max_fill_area=max_fill_area)
-            new_image[y + border:ymax, x + border:xmax] = filled[border:-border, border:-border]
-    return new_image
+    """process_full_tiles.py:214-224: tiles of ``tile_size`` every ``tile_size - 2*border`` pixels, each filled on its
+    own; only the part of a tile inside its ``border`` frame is written back, clipped ``border`` short of the raster."""
+    h, w = image.shape
+    out = image.copy()
+    step = tile_size - 2 * border
+    for top in range(0, h, step):
+        bottom = min(top + tile_size - border, h - border)
+        for left in range(0, w, step):
+            right = min(left + tile_size - border, w - border)
+            tile = interpolateMissingValues(image[top:top + tile_size, left:left + tile_size].copy(), no_value,
+                                            max_fill_area=max_fill_area)
+            out[top + border:bottom, left + border:right] = tile[border:-border, border:-border]
+    return out
 
 
 def preprocess(lib, handle, device, img: np.ndarray, dem: np.ndarray, no_value: float,

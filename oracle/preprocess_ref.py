@@ -131,43 +131,39 @@ def resize_cubic(src: np.ndarray, dsize_wh: Tuple[int, int]) -> np.ndarray:
 def interpolate_missing_values(data: np.ndarray, no_value: float, max_fill_area: int = 256) -> np.ndarray:
     """interpolateMissingValues, process_full_tiles.py:184-212 (in place on ``data``, which it also returns)."""
     from scipy import interpolate, ndimage
-    x = np.arange(0, data.shape[1])
-    y = np.arange(0, data.shape[0])
-    invalid_mask = data <= no_value
-    if not np.any(invalid_mask):
+    bad = data <= no_value
+    n_bad = int(bad.sum())
+    if n_bad == 0 or n_bad == bad.size:
         return data
-    if not np.any(~invalid_mask):
+    lab, n_lab = ndimage.label(bad, structure=np.ones((3, 3), dtype=bool))   # cv2 default: 8-connected
+    # the reference takes np.unique over the whole label image: label 0 (the valid pixels) is one of the "regions"
+    census = {k: int((lab == k).sum()) for k in range(n_lab + 1)}
+    if min(census.values()) > max_fill_area:
         return data
-    labels, _ = ndimage.label(invalid_mask, structure=np.ones((3, 3), dtype=bool))   # cv2 default: 8-connected
-    ids, counts = np.unique(labels, return_counts=True)     # label 0 = the valid pixels, counted like any region
-    if np.min(counts) > max_fill_area:
-        return data
-    xx, yy = np.meshgrid(x, y)
-    x1 = xx[~invalid_mask]
-    y1 = yy[~invalid_mask]
-    known_values = data[~invalid_mask]
-    interp_image = interpolate.griddata((x1, y1), known_values.ravel(), (xx, yy), method="cubic")
-    to_keep_mask = np.zeros_like(data, dtype=bool)
-    for id_, count in zip(ids, counts):
-        if count < max_fill_area:
-            to_keep_mask[labels == id_] = True
-    data[to_keep_mask] = interp_image[to_keep_mask]
+    yy, xx = np.indices(data.shape)
+    good = ~bad
+    cubic = interpolate.griddata((xx[good], yy[good]), data[good], (xx, yy), method="cubic")
+    for k, size in census.items():
+        if size < max_fill_area:
+            sel = lab == k
+            data[sel] = cubic[sel]
     return data
 
 
 def fill_nan(image: np.ndarray, no_value: float, tile_size: int = 1024, border: int = 128,
              max_fill_area: int = 256) -> np.ndarray:
     """fillNan, process_full_tiles.py:214-224: overlapping tiles, only each tile's interior is written back."""
-    new_image = image.copy()
-    stride = tile_size - border * 2
-    for y in range(0, image.shape[0], stride):
-        ymax = min(y + tile_size - border, image.shape[0] - border)
-        for x in range(0, image.shape[1], stride):
-            tmp = image[y:y + tile_size, x:x + tile_size]
-            xmax = min(x + tile_size - border, image.shape[1] - border)
-            filled = interpolate_missing_values(tmp.copy(), no_value, max_fill_area=max_fill_area)
-            new_image[y + border:ymax, x + border:xmax] = filled[border:-border, border:-border]
-    return new_image
+    result = np.array(image, copy=True)
+    rows, cols = image.shape
+    pitch = tile_size - border * 2
+    for y0 in range(0, rows, pitch):
+        y1 = min(y0 + tile_size - border, rows - border)
+        for x0 in range(0, cols, pitch):
+            x1 = min(x0 + tile_size - border, cols - border)
+            patch = np.array(image[y0:y0 + tile_size, x0:x0 + tile_size], copy=True)
+            patch = interpolate_missing_values(patch, no_value, max_fill_area=max_fill_area)
+            result[y0 + border:y1, x0 + border:x1] = patch[border:-border, border:-border]
+    return result
 
 
 def preprocess(img: np.ndarray, dem: np.ndarray, no_value: float) -> Tuple[np.ndarray, np.ndarray]:
