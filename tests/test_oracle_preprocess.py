@@ -102,6 +102,23 @@ def test_fill_nan_writes_tile_interiors_only():
     assert out.shape == img.shape
 
 
+def test_product_infilling_equals_oracle():
+    """moonsuperresolution_amd.preprocess keeps the in-filling on the host (SciPy, as the reference): it and the oracle
+    are written independently and must agree exactly, quirks included."""
+    from moonsuperresolution_amd import preprocess as pp
+    rng = np.random.default_rng(5)
+    img = surface(120, 150)
+    for _ in range(12):
+        y, x = int(rng.integers(0, 118)), int(rng.integers(0, 148))
+        img[y:y + int(rng.integers(1, 4)), x:x + int(rng.integers(1, 4))] = NOVAL
+    img[60:80, 90:120] = NOVAL
+    for kw in (dict(tile_size=32, border=8, max_fill_area=8), dict(tile_size=64, border=16, max_fill_area=24)):
+        assert np.array_equal(pp.fillNan(img.copy(), NOVAL, **kw), pr.fill_nan(img.copy(), NOVAL, **kw))
+    tiny = np.full((12, 12), NOVAL, np.float32)
+    tiny[0:2, 0:3] = 7.0
+    assert np.array_equal(pp.interpolateMissingValues(tiny.copy(), NOVAL, 24), pr.interpolate_missing_values(tiny.copy(), NOVAL, 24))
+
+
 def test_preprocess_square_raster():
     truth = surface(2048, 2048)
     dem = truth.copy()
