@@ -567,12 +567,15 @@ int alloc_padded(msr_handle* h, const std::string& key, int r, int C, Padded* ou
 // planner must agree: both call this.
 ConvVariant pick_conv_variant(int B, int rout, int N, int stride, int epi, int prec, int cin) {
     ConvVariant v;
-    v.tile = conv_pick_tile(B * rout * rout, N, epi, prec);
+    const int M = B * rout * rout;
+    v.tile = conv_pick_tile(M, N, epi, prec, 9 * (cin / 32));
     v.wt_frag = 0;
     if (prec == PREC_BF16X3) {
-        if (v.tile == TILE_64x64) v.wt_frag = 1;                          // B in VGPRs: +18 % on the small tile
-        else if (stride == 1 && rout >= 16 && cin % 64 == 0 &&
-                 (size_t)B * (rout + 2) * (rout + 2) * cin * sizeof(float) < ((size_t)1 << 31)) {   // raw buffer loads: 2 GiB
+        const long big_blocks = (long)((M + 127) / 128) * (N / 128);
+        if (v.tile == TILE_64x64 || big_blocks < 256) {
+            v.wt_frag = 1;   // few workgroups (with split-K): B fragments straight to VGPRs, +18 % on the small tile
+        } else if (stride == 1 && rout >= 16 && cin % 64 == 0 &&
+                   (size_t)B * (rout + 2) * (rout + 2) * cin * sizeof(float) < ((size_t)1 << 31)) {   // raw buffer loads: 2 GiB
             // LDS-staged input halo.  The 512-thread ping-pong form (one workgroup per CU, 16 x 16 pixels) is
             // 10-25 % faster as soon as it fills the chip once; below that, two 256-thread workgroups per CU.
             const long pp_blocks = (long)B * (rout / 16) * (rout / 16) * (N / 128);
@@ -597,7 +600,7 @@ Op conv_op(const Padded& in, const float* wt, const float* bias, int B, int rout
     const ConvVariant cv = pick_conv_variant(B, rout, N, stride, epi, prec, in.C);
     op.tile = cv.tile;
     c.wt_frag = cv.wt_frag;
-    c.ksplit = (op.tile == TILE_128x128_HALO || op.tile == TILE_128x128_HALO16 || op.tile == TILE_256x128_PP) ? 1 : conv_pick_ksplit(B * rout * rout, N, 9 * (in.C / 32), op.tile);
+    c.ksplit = (op.tile == TILE_128x128_HALO || op.tile == TILE_128x128_HALO16 || op.tile == TILE_256x128_PP) ? 1 : conv_pick_ksplit(B * rout * rout, N, 9 * (in.C / 32), op.tile, prec);
     c.partial = nullptr;   // bound to the handle's workspace at launch
     op.flops = 2.0 * B * rout * rout * (double)in.C * N * 9;
     return op;

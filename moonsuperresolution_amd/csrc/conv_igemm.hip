@@ -1573,7 +1573,7 @@ hipError_t launch_moments_from_slabs(const float* partial, int P, int C, float e
     return hipGetLastError();
 }
 
-int conv_pick_tile(int M, int N, int epilogue, int prec) {
+int conv_pick_tile(int M, int N, int epilogue, int prec, int ksteps) {
     // The big tile needs >= ~2 waves of workgroups per CU to hide its barrier; otherwise take the small one.
     // Measured on MI355X (tests/gpu_conv_bench.py): the 16-channel K-step (3 workgroups per CU) is ~8 % faster
     // than the 32-channel one for the SPADE epilogue (its long epilogue is covered by a third resident
@@ -1582,15 +1582,22 @@ int conv_pick_tile(int M, int N, int epilogue, int prec) {
     const long big_blocks = (long)((M + 127) / 128) * (N / 128);
     if (N % 128 == 0 && big_blocks >= (prec == PREC_BF16X3 ? 256 : 512))
         return (epilogue == EPI_SPADE && prec == PREC_F32) ? TILE_128x128_K16 : TILE_128x128;
+    // Few pixels, long K (the r <= 8 main convs, r = 16 at small batch): these layers stream their weights, and the
+    // 128-row tile reads each weight for twice as many pixels; split-K (>= 72 K-steps) supplies the workgroups.
+    // tests/gpu_smalltile_sweep.py: 93 -> 70 us (B=16, r=8, 1024 -> 1024), 171 -> 120 us (B=8, r=16).
+    if (prec == PREC_BF16X3 && N % 128 == 0 && M >= 128 && ksteps >= 72 && big_blocks * 16 >= 256) return TILE_128x128;
     return TILE_64x64;
 }
 
-int conv_pick_ksplit(int M, int N, int ksteps, int tile) {
+int conv_pick_ksplit(int M, int N, int ksteps, int tile, int prec) {
     // Low-resolution layers (M = B*r*r of a few hundred pixels) do not produce enough tiles to fill 256 CUs:
     // cut K so that about 1024 small (512 big) workgroups exist.  Every range keeps >= 4 K-steps.
     const int bm = tile == TILE_64x64 ? 64 : 128;
     const long blocks = (long)((M + bm - 1) / bm) * (N / bm);
-    const long want = tile == TILE_64x64 ? 1024 : 512;
+    long want = tile == TILE_64x64 ? 1024 : 512;
+    // short K at bf16 rates (the gamma/beta convs, 36 K-steps): the split-K pass costs more than it buys beyond one
+    // workgroup per CU (tests/gpu_smalltile_sweep.py: 28 vs 33 us at B=16, r=8)
+    if (prec == PREC_BF16X3 && ksteps < 72) want = 256;
     int ks = 1;
     while (blocks * ks < want && ks < 16 && ksteps / (ks * 2) >= 4) ks *= 2;
     return ks;

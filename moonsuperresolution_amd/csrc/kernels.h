@@ -106,8 +106,8 @@ enum ConvTile : int { TILE_128x128 = 0, TILE_64x64 = 1, TILE_128x128_K16 = 2, TI
 hipError_t conv_igemm_init();   // sets dynamic-LDS attributes once
 hipError_t launch_conv_igemm(const ConvParams& p, int epilogue, int tile, hipStream_t s);
 // picks the tile and the K split for a problem size (fills the chip for the low-resolution layers)
-int conv_pick_tile(int M, int N, int epilogue, int prec);
-int conv_pick_ksplit(int M, int N, int ksteps, int tile);
+int conv_pick_tile(int M, int N, int epilogue, int prec, int ksteps = 0);
+int conv_pick_ksplit(int M, int N, int ksteps, int tile, int prec = PREC_F32);
 // number of partial-moment slabs the fused epilogue of this launch writes (0 if the shape is not tileable)
 int conv_stat_slabs(const ConvParams& p, int tile);
 // Chan-combines the slabs in fp64: mean and sqrt(biased var + eps) per channel (deterministic order)
