@@ -1,34 +1,45 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the tiled DEM super-resolution hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload spade256|spade512]
-
-Conv arithmetic (--precision): "bf16x3" (default) = 3-term split-bf16 products on v_mfma_f32_32x32x16_bf16 with fp32
-accumulation, inputs / outputs / weights / all other ops fp32 — 2e-5 relative L-inf vs the float64 oracle, inside the
-1e-3 bar of BASELINE.json (tests/test_gpu_generator.py); "fp32" = exact fp32 MFMA (4e-6).
+    python bench.py --gpus N --steps K --warmup W [--workload spade512|spade256] [--precision bf16x3|fp32]
 
 A "step" is one generator(call) — `self.model(np.array(batch), training=False)` of process_full_tiles.py:338 —
 over one batch of synthetic (ortho, low-res DEM) patches that is already resident in HBM:
-    spade256 (default, BASELINE.json configs[1]): GauGAN(256, 16, 256), batch [16,256,256,2] = 4 tiles of 512x512
-    spade512 (configs[2], the MFMA roofline run):  GauGAN(512,  8, 256), batch [ 8,512,512,2] = 8 tiles of 512x512
+    spade512 (default, BASELINE.json configs[2], the largest single-GPU config = "the MFMA roofline run"):
+              GauGAN(512,  8, 256), batch [ 8,512,512,2] = 8 tiles of 512x512 per step
+    spade256 (configs[1]): GauGAN(256, 16, 256), batch [16,256,256,2] = 4 tiles of 512x512 per step
 Metric: 512x512 DEM tiles/s over the whole job (a 512x512 tile = four 256x256 patches).
-N > 1: one process per GPU (torch.distributed / RCCL only for the timing barrier + max); patches are
-independent units, so ranks share nothing on the data path ("weak" scaling: per-GPU work is fixed).
---streams 2 issues consecutive steps (independent batches) alternately on two generator handles, each on its own HIP
-stream: the latency-bound head of one call (encoder, dense, the r <= 8 layers: ~20 % of a call at low occupancy) then
-overlaps the matrix-bound tail of the other (+5-7 % throughput; the driver's tile loop, tiler.py, does this by
-default).  The default is ONE stream, so that the per-launch durations bench.py reports and a rocprofv3 kernel trace
-of the same command agree (overlapping kernels of two streams stretch each other's traced durations).
-`p50_ms_per_call` / `p50_latency_ms_per_tile` come from a single-stream pass after the timed region.
+
+Conv arithmetic (--precision): "bf16x3" (default) = 3-term split-bf16 products on v_mfma_f32_16x16x32_bf16 with fp32
+accumulation, inputs / outputs / weights / all other ops fp32 — ~2e-5 relative L-inf vs the float64 oracle, inside the
+1e-3 bar of BASELINE.json (tests/test_gpu_baseline_configs.py runs these very shapes); "fp32" = exact fp32 MFMA.
+
+At N = 1 the one JSON line also carries, under "also", the driver-timed figures of the other single-GPU
+configurations (spade256 in bf16x3 and in fp32: value, ms_per_step, roofline each, same K and W), the B = 1
+single-call latency ("p50_ms_per_call_b1"), and the CPU baseline.
+
+N > 1: `python bench.py --gpus N` launches its own N workers (fresh child processes of torch.distributed.run, before
+this process touches HIP); under an outer `python -m torch.distributed.run ... bench.py --gpus N` (WORLD_SIZE set) it
+is a worker.  One process per GPU, RCCL process group.  Patches are independent units, so ranks share nothing while
+generating ("weak" scaling: per-GPU work is fixed); the path's one exchange — the all-gather of the finished rows of
+the map (moonsuperresolution_amd.distributed.all_gather_rows, what process_map_sharded ends with) — is inside the
+timed region, sized to the rows the timed steps complete (K * B patches x stride^2 unique pixels each at the
+recommended stride S/8, mean + std float32 and good uint8).
+--streams 2 issues consecutive steps alternately on two generator handles / HIP streams (+5-7 %; the driver's tile
+loop, tiler.py, does this by default).  The default is ONE stream, so that the per-launch durations reported here and a
+rocprofv3 kernel trace of the same command agree.
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
+import sys
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # 2 call streams + 2 auxiliary streams + torch's own: keep them on separate queues
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
 import statistics
-import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -36,12 +47,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    "spade256": dict(S=256, B=16, name="SPADE-256 GauGAN(256,16,256) batch=16 256x256 patches (=4 512x512 tiles) per step"),
-    "spade512": dict(S=512, B=8, name="SPADE-512 GauGAN(512,8,256) batch=8 512x512 tiles per step"),
+    "spade512": dict(S=512, B=8, name="SPADE-512 GauGAN(512,8,256) batch=8 512x512 tiles per step (BASELINE configs[2])"),
+    "spade256": dict(S=256, B=16, name="SPADE-256 GauGAN(256,16,256) batch=16 256x256 patches (=4 512x512 tiles) per step "
+                                      "(BASELINE configs[1])"),
 }
 # MI355X_MICROARCH.md: dense MFMA peaks.  For bf16x3 every algorithmic product costs three bf16 MFMA products, so
-# the algorithmic ceiling is a third of the bf16 peak; `achieved` stays ALGORITHMIC FLOP/s in both cases.
+# the algorithmic ceiling is a third of the bf16 peak; `achieved` stays ALGORITHMIC FLOP/s in every mode.
 PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0}
+MFMA_PER_PRODUCT = {"fp32": 1, "bf16x3": 3}
+DTYPE = {"fp32": "f32", "bf16x3": "bf16x3 (f32 in/out/accumulate)"}
 
 
 def host_threads() -> int:
@@ -61,9 +75,9 @@ def host_threads() -> int:
 
 
 def pmc_traffic(workload: str):
-    """HBM bytes per conv_igemm_f32 launch from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json,
-    produced by profiles/summarize_pmc.py: separate FETCH_SIZE / WRITE_SIZE passes, KiB units, FETCH doubled on
-    gfx950 as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside this process."""
+    """HBM bytes per conv launch from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json, produced by
+    profiles/summarize_pmc.py: separate FETCH_SIZE / WRITE_SIZE passes, KiB units, FETCH doubled on gfx950 as
+    MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside this process.  Newest round wins."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
@@ -96,52 +110,80 @@ def cpu_baseline(S: int, sample_patches: int, weights, eps_full):
                        f"patches of {S}x{S} = {tiles:g} tiles, {dt:.1f} s")
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="spade256")
-    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="bf16x3",
-                    help="conv arithmetic: exact fp32 MFMA, or 3-term split-bf16 on the bf16 MFMA (fp32 accumulate)")
-    ap.add_argument("--streams", type=int, default=1, help="generator handles / HIP streams the steps alternate over")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
-    args = ap.parse_args()
+def self_launch(args) -> None:
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as fresh child processes (this process
+    has not imported torch or touched HIP) and exit with their code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
 
-    import numpy as np
+
+class Dist:
+    """The process group of a run: RCCL ("nccl") on the GPUs; MSR_BENCH_BACKEND=gloo (+ MSR_BENCH_DEVICE) rehearses
+    the N > 1 plumbing on a one-GPU box, moving tensors through the host for its collectives."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        if "MSR_BENCH_DEVICE" in os.environ:
+            self.local = int(os.environ["MSR_BENCH_DEVICE"])
+        torch.cuda.set_device(self.local)
+        self.backend = os.environ.get("MSR_BENCH_BACKEND", "nccl")
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                        device_id=torch.device("cuda", self.local))
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max(self, v: float) -> float:
+        if self.world == 1:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_rows(self, products, n_rows, T):
+        """The path's exchange step: all-gather of the finished rows of every product."""
+        from moonsuperresolution_amd.distributed import all_gather_rows
+        out = []
+        for t in products:
+            if self.backend != "nccl":
+                t = t.cpu()
+            out.append(all_gather_rows(t, n_rows, T, self.world))
+        return out
+
+    def close(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+def run_workload(args, D: Dist, workload: str, precision: str, with_cpu: bool, with_b1: bool):
+    """Warm up, time exactly K steps between barriers, and return the result dict of one (workload, precision)."""
     import torch
-    import torch.distributed as dist
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
-    # Rehearsal knobs (one-GPU boxes only): MSR_BENCH_DEVICE pins every rank to one device and MSR_BENCH_BACKEND=gloo
-    # replaces RCCL, so the N>1 plumbing can be exercised without N GPUs.  The driver's runs set neither.
-    if "MSR_BENCH_DEVICE" in os.environ:
-        local = int(os.environ["MSR_BENCH_DEVICE"])
-    torch.cuda.set_device(local)
-    backend = os.environ.get("MSR_BENCH_BACKEND", "nccl")
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
     from moonsuperresolution_amd import Generator, make_latent_noise, make_weights, synthetic_patches
-
-    wl = WORKLOADS[args.workload]
+    wl = WORKLOADS[workload]
     S, B = wl["S"], wl["B"]
+    rank, world, local = D.rank, D.world, D.local
     weights = make_weights("gaugan", S, seed=1234)
     eps = make_latent_noise(B, 256, seed=7)
     ns = max(1, args.streams)
-    gens = [Generator(S, B, variant="gaugan", weights=weights, eps=eps, device=local, precision=args.precision)
+    gens = [Generator(S, B, variant="gaugan", weights=weights, eps=eps, device=local, precision=precision)
             for _ in range(ns)]
     gen = gens[0]
     streams = [torch.cuda.Stream() for _ in range(ns)]
@@ -149,16 +191,23 @@ def main():
     pool = [torch.from_numpy(synthetic_patches(B, S, seed=1000 * rank + i)).cuda() for i in range(2)]
     outs = [torch.empty((B, S, S, 1), dtype=torch.float32, device="cuda") for _ in range(ns)]
     out = outs[0]
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    # N > 1: the finished rows the K timed steps complete (see the module docstring); T-row blocks, one per rank
+    stride = S // 8
+    T = 1024
+    rows_px = args.steps * B * stride * stride
+    width = 4 * T
+    n_blocks = max(1, -(-rows_px // (width * T)))
+    products = None
+    if world > 1:
+        products = [torch.zeros((n_blocks * T, width), dtype=torch.float32, device="cuda"),
+                    torch.zeros((n_blocks * T, width), dtype=torch.float32, device="cuda"),
+                    torch.zeros((n_blocks * T, width), dtype=torch.uint8, device="cuda")]
+        D.gather_rows(products, n_blocks * world, T)          # warm the communicator (ring set-up, IPC handles)
 
     for i in range(max(args.warmup, ns)):
         with torch.cuda.stream(streams[i % ns]):
             gens[i % ns].forward_device(pool[i % len(pool)], out=outs[i % ns])
-    barrier()
+    D.barrier()
     for g in gens:
         g.profile(0 if args.no_profile else 2)    # dominant kernel family only, one event pair per run of launches
     ref = torch.cuda.Event(enable_timing=True)
@@ -167,12 +216,16 @@ def main():
     for i in range(args.steps):
         with torch.cuda.stream(streams[i % ns]):
             gens[i % ns].forward_device(pool[i % len(pool)], out=outs[i % ns])
-    barrier()
-    elapsed = time.perf_counter() - t0
+    t_gather = 0.0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        gathered = D.gather_rows(products, n_blocks * world, T)
+        torch.cuda.synchronize()
+        t_gather = time.perf_counter() - tg
+        assert gathered[0].shape[0] == n_blocks * world * T
+    D.barrier()
+    elapsed = D.max(time.perf_counter() - t0)
     stats = {}
     if not args.no_profile:
         for g in gens:
@@ -218,60 +271,118 @@ def main():
         gen.profile(False)
 
     tiles_per_step = B * (S / 512.0) ** 2
-    value = world * args.steps * tiles_per_step / elapsed
-    if rank == 0:
-        res = {
-            "metric": "512x512 DEM tiles/s (whole job)", "value": value, "unit": "tiles/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16x3 (f32 in/out/accumulate)",
-            "data": "synthetic",
-            "config": {"workload": wl["name"], "image_size": S, "batch_size": B, "variant": "gaugan",
-                       "weights": "random-init (Keras default distributions), seed 1234",
-                       "tiles_per_step_per_gpu": tiles_per_step, "parallelism": f"tile-sharded x{world}",
-                       "streams_per_gpu": ns},
-            "patches_per_s": world * args.steps * B / elapsed,
-            "p50_latency_ms_per_tile": statistics.median(step_ms) / tiles_per_step,
-            "p50_ms_per_call": statistics.median(step_ms),
-            "latency_note": f"p50 of {lat_n} calls on one stream with nothing else in flight (after the timed region)",
-            "forward_gflop_per_call": gen.forward_flops() / 1e9,
-            "achieved_tflops_whole_call": gen.forward_flops() * args.steps / elapsed / 1e12,
-            "device_mem_gib": ns * gen.device_bytes() / 2 ** 30,
-        }
-        kname = "conv_igemm_f32" if args.precision == "fp32" else "conv_igemm_bf16x3"
-        conv = stats.get(kname)
-        if conv and conv_union_ms > 0:
-            ach = conv["flops"] / (conv_union_ms * 1e-3) / 1e12
-            peak = PEAK_TFLOPS[args.precision]
-            res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach,
-                               "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                               "traffic": None, "traffic_unit": "bytes per launch (HBM, PMC)",
-                               "launches": conv["launches"],
-                               "avg_launch_ms": conv_union_ms / conv["launches"],
-                               "family_busy_ms": conv_union_ms, "sum_of_intervals_ms": conv["device_ms"]}
-            res["roofline"]["algorithmic_flops_per_launch"] = conv["flops"] / conv["launches"]
-            if args.precision == "bf16x3":
-                res["roofline"]["mfma_executed_tflops"] = 3 * ach   # three bf16 MFMA products per algorithmic one
-                res["roofline"]["frac_of_executed_mfma_peak"] = 3 * ach / peak
-                res["roofline"]["note"] = ("frac = algorithmic FLOP/s over the dense bf16 MFMA peak; bf16x3 issues three bf16 "
-                                           "MFMA products per algorithmic product, so the matrix pipe executes 3x `achieved` "
-                                           "(frac_of_executed_mfma_peak); SQ_VALU_MFMA_BUSY_CYCLES of the dominant kernel: "
-                                           "profiles/r01_spade256_bf16x3_sq_counters.txt (80 % long-K, 70 % gamma/beta layers "
-                                           "at the ~1.94 GHz the chip holds under this load)")
-            pmc = pmc_traffic(args.workload + ("" if args.precision == "fp32" else "_bf16x3"))
-            if pmc and "conv_igemm" in pmc[0]:
-                res["roofline"]["traffic"] = pmc[0]["conv_igemm"]["hbm_bytes_per_forward"] / (conv["launches"] / args.steps)
-                res["roofline"]["traffic_source"] = "profiles/" + pmc[1]
-            res["roofline"]["timing"] = ("HIP events on the calls' streams over the timed region, one pair per run of "
-                                         "consecutive conv launches (inter-launch gaps of a run included); family time "
-                                         "= union of the intervals over the streams")
-            res["kernel_ms_per_call"] = {k: v["device_ms"] / extra for k, v in all_stats.items()}
-            res["kernel_ms_per_call_note"] = f"separate pass of {extra} calls after the timed region, every launch bracketed"
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(S, B, weights, eps)
-        print(json.dumps(res))
+    res = {
+        "metric": "512x512 DEM tiles/s (whole job)", "value": world * args.steps * tiles_per_step / elapsed,
+        "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": DTYPE[precision], "data": "synthetic",
+        "config": {"workload": wl["name"], "image_size": S, "batch_size": B, "variant": "gaugan",
+                   "weights": "random-init (Keras default distributions), seed 1234",
+                   "tiles_per_step_per_gpu": tiles_per_step, "parallelism": f"tile-sharded x{world}",
+                   "streams_per_gpu": ns},
+        "patches_per_s": world * args.steps * B / elapsed,
+        "p50_latency_ms_per_tile": statistics.median(step_ms) / tiles_per_step,
+        "p50_ms_per_call": statistics.median(step_ms),
+        "latency_note": f"p50 of {lat_n} calls on one stream with nothing else in flight (after the timed region)",
+        "forward_gflop_per_call": gen.forward_flops() / 1e9,
+        "achieved_tflops_whole_call": world * gen.forward_flops() * args.steps / elapsed / 1e12,
+        "device_mem_gib": ns * gen.device_bytes() / 2 ** 30,
+    }
     if world > 1:
-        dist.destroy_process_group()
+        res["exchange"] = {"collective": f"all_gather_into_tensor x3 ({D.backend}) of the finished rows, inside the timed region",
+                           "bytes_per_rank": n_blocks * T * width * 9, "seconds_rank0": t_gather}
+    kname = "conv_igemm_f32" if precision == "fp32" else "conv_igemm_bf16x3"
+    conv = stats.get(kname)
+    if conv and conv_union_ms > 0:
+        ach = conv["flops"] / (conv_union_ms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[precision]
+        rl = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+              "traffic": None, "traffic_unit": "bytes per launch (HBM, PMC)", "launches": conv["launches"],
+              "avg_launch_ms": conv_union_ms / conv["launches"], "family_busy_ms": conv_union_ms,
+              "sum_of_intervals_ms": conv["device_ms"],
+              "algorithmic_flops_per_launch": conv["flops"] / conv["launches"]}
+        if MFMA_PER_PRODUCT[precision] > 1:
+            k = MFMA_PER_PRODUCT[precision]
+            rl["mfma_executed_tflops"] = k * ach
+            rl["frac_of_executed_mfma_peak"] = k * ach / peak
+            rl["note"] = (f"frac = algorithmic FLOP/s over the dense bf16 MFMA peak; {precision} issues {k} bf16 MFMA "
+                          "products per algorithmic product, so the matrix pipe executes that multiple of `achieved` "
+                          "(frac_of_executed_mfma_peak) and frac is capped at 1/" + str(k))
+        pmc = pmc_traffic(workload + ("" if precision == "fp32" else "_" + precision))
+        if pmc and "conv_igemm" in pmc[0]:
+            rl["traffic"] = pmc[0]["conv_igemm"]["hbm_bytes_per_forward"] / (conv["launches"] / args.steps)
+            rl["traffic_source"] = "profiles/" + pmc[1]
+        rl["timing"] = ("HIP events on the calls' streams over the timed region, one pair per run of consecutive conv "
+                        "launches (inter-launch gaps of a run included); family time = union of the intervals over the "
+                        "streams")
+        res["roofline"] = rl
+        res["kernel_ms_per_call"] = {k: v["device_ms"] / extra for k, v in all_stats.items()}
+        res["kernel_ms_per_call_note"] = f"separate pass of {extra} calls after the timed region, every launch bracketed"
+    for g in gens:
+        g.close()
+    del gens, gen, pool, outs
+    torch.cuda.empty_cache()
+    if with_b1:
+        # single-call latency at B = 1 (the serial call of process_full_tiles.py:338 with one patch in flight)
+        g1 = Generator(S, 1, variant="gaugan", weights=weights, eps=eps[:1], device=local, precision=precision)
+        x1 = torch.from_numpy(synthetic_patches(1, S, seed=5)).cuda()
+        o1 = torch.empty((1, S, S, 1), dtype=torch.float32, device="cuda")
+        for _ in range(5):
+            g1.forward_device(x1, out=o1)
+        torch.cuda.synchronize()
+        lat = []
+        for _ in range(30):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            g1.forward_device(x1, out=o1)
+            b.record()
+            b.synchronize()
+            lat.append(a.elapsed_time(b))
+        res["p50_ms_per_call_b1"] = statistics.median(lat)
+        res["p50_ms_per_call_b1_note"] = f"GauGAN({S},1,256): median of 30 single calls, each synchronised, B = 1"
+        g1.close()
+        del g1
+        torch.cuda.empty_cache()
+    if with_cpu:
+        res["cpu_baseline"] = cpu_baseline(S, B, weights, eps)
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="spade512")
+    ap.add_argument("--precision", choices=sorted(PEAK_TFLOPS), default="bf16x3",
+                    help="conv arithmetic: exact fp32 MFMA, or 3-term split-bf16 on the bf16 MFMA (fp32 accumulate)")
+    ap.add_argument("--streams", type=int, default=1, help="generator handles / HIP streams the steps alternate over")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the other single-GPU configurations and the B=1 latency")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    D = Dist(args)
+    solo = D.world == 1
+    res = run_workload(args, D, args.workload, args.precision, with_cpu=solo and not args.no_cpu_baseline,
+                       with_b1=solo and not args.no_also)
+    if solo and not args.no_also:
+        also = {}
+        for wl, prec in (("spade256", "bf16x3"), ("spade256", "fp32"), ("spade512", "fp32")):
+            if (wl, prec) == (args.workload, args.precision) or (wl, prec) == ("spade512", "fp32"):
+                continue
+            r = run_workload(args, D, wl, prec, with_cpu=False, with_b1=False)
+            also[f"{wl}_{prec}"] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config",
+                                                       "p50_ms_per_call", "roofline") if k in r}
+        res["also"] = also
+    if D.rank == 0:
+        print(json.dumps(res))
+    D.close()
 
 
 if __name__ == "__main__":

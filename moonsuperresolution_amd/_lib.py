@@ -68,14 +68,44 @@ SYMBOLS = [
 _lib: Optional[C.CDLL] = None
 
 
-def build(verbose: bool = False) -> str:
+STAMP_PATH = os.path.join(CSRC, ".build_stamp")
+
+
+def sources_hash() -> str:
+    """SHA-256 over the library's sources (csrc/*.hip, *.cpp, *.h, Makefile and include/moonsr.h)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h")) or f == "Makefile")
+    for f in [os.path.join(CSRC, f) for f in files] + [os.path.join(_HERE, "..", "include", "moonsr.h")]:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def is_stale() -> bool:
+    """True if the .so is missing or was built from other sources than the ones in the tree (the .so is git-ignored,
+    and file times do not survive a snapshot, so the check is by content: csrc/.build_stamp holds the hash)."""
+    if not os.path.exists(LIB_PATH) or not os.path.exists(STAMP_PATH):
+        return True
+    with open(STAMP_PATH) as fh:
+        return fh.read().strip() != sources_hash()
+
+
+def build(verbose: bool = False, force: bool = False) -> str:
     """Compile libmoonsr_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force or is_stale():
+        for f in os.listdir(CSRC):          # objects of an older source state: make only compares file times
+            if f.endswith(".o") and force:
+                os.remove(os.path.join(CSRC, f))
     res = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
     if verbose or res.returncode:
         print(res.stdout[-4000:])
         print(res.stderr[-4000:])
     if res.returncode:
         raise RuntimeError("building libmoonsr_hip.so failed (see output above)")
+    with open(STAMP_PATH, "w") as fh:
+        fh.write(sources_hash() + "\n")
     return LIB_PATH
 
 

@@ -7,7 +7,10 @@ namespace msr {
 
 // ------------------------------------------------------------------------------------------------
 // patch_stats: getPatch's validity test + normalize's four reductions for every patch of a tile
-// (process_full_tiles.py:286-292, 307-309).  One workgroup per patch; min/max are exact.
+// (process_full_tiles.py:286-292, 307-309).  One workgroup per patch; min/max are exact.  NumPy's .min() / .max()
+// return NaN as soon as one pixel is NaN (fminf / fmaxf would drop it), so a NaN flag per raster is reduced beside
+// the extrema and turns both of that raster's figures into NaN: the whole patch then normalises to NaN like the
+// reference's (a NaN pixel is not <= no_value, so the patch stays valid in both).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) patch_stats_kernel(const float* __restrict__ img, const float* __restrict__ dem,
                                                           int rows, int cols, const int* __restrict__ ox,
@@ -18,7 +21,7 @@ __global__ void __launch_bounds__(256) patch_stats_kernel(const float* __restric
     const int i = blockIdx.x;
     const int x0 = ox[i], y0 = oy[i];
     float imn = INFINITY, imx = -INFINITY, dmn = INFINITY, dmx = -INFINITY;
-    int anybad = 0;
+    int anybad = 0, inan = 0, dnan = 0;
     if (x0 < 0 || y0 < 0 || x0 + S > cols || y0 + S > rows) {
         anybad = 1;   // outside the canvas: not a patch the reference could cut
     } else {
@@ -41,6 +44,8 @@ __global__ void __launch_bounds__(256) patch_stats_kernel(const float* __restric
             dmx = fmaxf(fmaxf(dmx, d.x), fmaxf(fmaxf(d.y, d.z), d.w));
             anybad |= (a.x <= no_value) | (a.y <= no_value) | (a.z <= no_value) | (a.w <= no_value) |
                       (d.x <= no_value) | (d.y <= no_value) | (d.z <= no_value) | (d.w <= no_value);
+            inan |= (a.x != a.x) | (a.y != a.y) | (a.z != a.z) | (a.w != a.w);
+            dnan |= (d.x != d.x) | (d.y != d.y) | (d.z != d.z) | (d.w != d.w);
         }
     }
 #pragma unroll
@@ -50,11 +55,13 @@ __global__ void __launch_bounds__(256) patch_stats_kernel(const float* __restric
         dmn = fminf(dmn, __shfl_xor(dmn, o));
         dmx = fmaxf(dmx, __shfl_xor(dmx, o));
         anybad |= __shfl_xor(anybad, o);
+        inan |= __shfl_xor(inan, o);
+        dnan |= __shfl_xor(dnan, o);
     }
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
         red[wave][0] = imn; red[wave][1] = imx; red[wave][2] = dmn; red[wave][3] = dmx;
-        bad[wave] = anybad;
+        bad[wave] = anybad | (inan << 1) | (dnan << 2);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -63,9 +70,10 @@ __global__ void __launch_bounds__(256) patch_stats_kernel(const float* __restric
             red[0][2] = fminf(red[0][2], red[w][2]); red[0][3] = fmaxf(red[0][3], red[w][3]);
             bad[0] |= bad[w];
         }
-        valid[i] = bad[0] ? 0 : 1;
-        minmax[4 * i + 0] = red[0][0]; minmax[4 * i + 1] = red[0][1];
-        minmax[4 * i + 2] = red[0][2]; minmax[4 * i + 3] = red[0][3];
+        valid[i] = (bad[0] & 1) ? 0 : 1;
+        const float qnan = __builtin_nanf("");
+        minmax[4 * i + 0] = (bad[0] & 2) ? qnan : red[0][0]; minmax[4 * i + 1] = (bad[0] & 2) ? qnan : red[0][1];
+        minmax[4 * i + 2] = (bad[0] & 4) ? qnan : red[0][2]; minmax[4 * i + 3] = (bad[0] & 4) ? qnan : red[0][3];
     }
 }
 

@@ -9,7 +9,7 @@ on GPUs, "gloo" in the CPU tests).
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, List, Sequence, Tuple
+from typing import Callable, List, Sequence, Tuple
 
 import numpy as np
 
@@ -18,15 +18,49 @@ def tile_rows(tiles: Sequence[Tuple[int, int]]) -> List[int]:
     return sorted({yy for _, yy in tiles})
 
 
+def rows_of_rank(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
+    """(first, count) of the contiguous block of tile rows rank owns; sizes differ by at most one."""
+    base, extra = divmod(n_rows, world)
+    return rank * base + min(rank, extra), base + (1 if rank < extra else 0)
+
+
 def shard_tile_rows(tiles: Sequence[Tuple[int, int]], rank: int, world: int) -> List[Tuple[int, int]]:
     """Contiguous blocks of tile rows per rank, sizes differing by at most one (15 rows on 8 ranks: 2,2,2,2,2,2,2,1)."""
     if not 0 <= rank < world:
         raise ValueError("rank out of range")
     rows = tile_rows(tiles)
-    base, extra = divmod(len(rows), world)
-    start = rank * base + min(rank, extra)
-    mine = set(rows[start:start + base + (1 if rank < extra else 0)])
+    start, count = rows_of_rank(len(rows), rank, world)
+    mine = set(rows[start:start + count])
     return [t for t in tiles if t[1] in mine]
+
+
+def all_gather_rows(local, n_rows: int, T: int, world: int):
+    """All-gather the finished rows of one product over the process group (RCCL on GPUs, gloo on CPU tensors).
+
+    local: this rank's [count * T, width] tensor (count = rows_of_rank(n_rows, rank, world)[1]).  Ranks own different
+    numbers of tile rows, so every rank contributes a block padded to the largest count; ONE collective writes all
+    blocks into one [world * max, width] buffer, which is then compacted in place (ranks with the larger count come
+    first, so only blocks after the first short rank move, towards the front) and returned as [n_rows * T, width].
+    Peak memory = that buffer + the padded block — not world copies of it."""
+    import torch
+    import torch.distributed as dist
+    base, extra = divmod(n_rows, world)
+    max_rows = (base + (1 if extra else 0)) * T
+    width = local.shape[1]
+    if local.shape[0] == max_rows:
+        block = local.contiguous()
+    else:
+        block = torch.zeros((max_rows, width), dtype=local.dtype, device=local.device)
+        block[:local.shape[0]] = local
+    out = torch.empty((world * max_rows, width), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, block)
+    if extra:   # ranks >= extra hold base rows: close the T-row gap behind each of them
+        dst = (extra * (base + 1) + base) * T
+        for r in range(extra + 1, world):
+            src = r * max_rows
+            out[dst:dst + base * T] = out[src:src + base * T].clone()
+            dst += base * T
+    return out[:n_rows * T]
 
 
 def process_map_sharded(shape: Tuple[int, int], tile_size: int, tiles: Sequence[Tuple[int, int]],
@@ -56,18 +90,7 @@ def process_map_sharded(shape: Tuple[int, int], tile_size: int, tiles: Sequence[
         std[r0:r0 + T, xx:xx + T] = torch.as_tensor(s).to(dev)
         good[r0:r0 + T, xx:xx + T] = torch.as_tensor(g).to(dev)
     if world > 1 and gather:
-        import torch.distributed as dist
-        # ranks own different numbers of rows: pad to the maximum, all_gather, trim
-        base, extra = divmod(len(rows), world)
-        max_rows = (base + (1 if extra else 0)) * T
-        outs = []
-        for t in (mean, std, good):
-            pad = torch.zeros((max_rows, width), dtype=t.dtype, device=dev)
-            pad[:t.shape[0]] = t
-            parts = [torch.empty_like(pad) for _ in range(world)]
-            dist.all_gather(parts, pad)
-            outs.append(torch.cat([p[:(base + (1 if r < extra else 0)) * T] for r, p in enumerate(parts)], dim=0))
-        mean, std, good = outs
+        mean, std, good = (all_gather_rows(t, len(rows), T, world) for t in (mean, std, good))
     elif world > 1:
         full = [torch.zeros((len(rows) * T, width), dtype=t.dtype, device=dev) for t in (mean, std, good)]
         if my_rows:

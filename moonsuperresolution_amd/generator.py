@@ -68,15 +68,20 @@ class Generator:
                 raise ValueError(f"eps must be [{batch_size}, {latent_dim}], got {e.shape}")
             self._eps_fixed = torch.from_numpy(e).to(self.device)
         self._ctor = dict(image_size=image_size, batch_size=batch_size, latent_dim=latent_dim, variant=variant,
-                          weights=weights, eps=eps, device=device, precision=precision)
+                          eps=eps, device=device, precision=precision)
+        self._weights: Optional[Mapping[str, np.ndarray]] = None   # what the handle holds now (clone() re-uploads it)
+        self.weights_version = 0                                    # bumped by every load(); the tiler's clones follow it
         if isinstance(weights, (int, np.integer)):
             weights = make_weights(variant, image_size, latent_dim, seed=int(weights))
         self.load(weights)
 
     def clone(self) -> "Generator":
-        """A second handle with the same weights (its own workspace), for issuing independent calls on another
-        stream: the latency-bound head of one call then overlaps the matrix-bound tail of the other."""
-        return Generator(**self._ctor)
+        """A second handle with the weights this handle holds NOW (the last ``load``, not the constructor's), its own
+        workspace: for issuing independent calls on another stream, where the latency-bound head of one call overlaps
+        the matrix-bound tail of the other."""
+        twin = Generator(weights=self._weights, **self._ctor)
+        twin.weights_version = self.weights_version
+        return twin
 
     # -- weights -----------------------------------------------------------------------------------
     def load(self, weights: Mapping[str, np.ndarray]) -> None:
@@ -92,6 +97,8 @@ class Generator:
             shp = (C.c_int64 * a.ndim)(*a.shape)
             rc = self._lib.msr_load_weight(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), shp, a.ndim)
             _lib.raise_for(self._lib, self._h, rc, f"msr_load_weight({name})")
+        self._weights = {name: weights[name] for name in expected}
+        self.weights_version += 1
 
     # -- the call ------------------------------------------------------------------------------------
     def forward_device(self, batch: torch.Tensor, eps: Optional[torch.Tensor] = None,

@@ -93,6 +93,8 @@ class DEMSuperResolution:
         self._pstreams = None
         S, s = self.image_size, self.stride
         if S < 64 or S & (S - 1):
+            # narrower than the reference (any size): the generator's six 2x up-samplings from S/64 and the conv
+            # kernels' power-of-two pixel tiles fix S to 64 * 2^k; documented in INTEGRATION.md
             raise ValueError("image_size must be a power of two >= 64")
         if s <= 0 or s > S:
             raise ValueError("stride must be in (0, image_size]")
@@ -282,6 +284,10 @@ class DEMSuperResolution:
                 # Patches go from the rasters to `preds` without leaving HBM.
                 if self._gens is None:
                     self._make_pipeline()
+                for g in self._gens[1:]:       # a load() on the base generator after construction: the clones follow
+                    if g.weights_version != self._gen.weights_version:
+                        g.load(self._gen._weights)
+                        g.weights_version = self._gen.weights_version
                 cur = torch.cuda.current_stream(dev)
                 batches = [torch.empty((B, S, S, 2), dtype=torch.float32, device=dev) for _ in self._gens]
                 for st in self._pstreams:

@@ -2,7 +2,10 @@
 """raster_bench.py — BASELINE config 4: process_full_tiles over a synthetic DEM raster, tile-row sharded.
 
     python raster_bench.py --rows 4096 --cols 4096 --image-size 256 --stride 32 --batch-size 16
-    python -m torch.distributed.run --nproc-per-node N raster_bench.py --gpus N --rows 15000 --cols 70000 ...
+    python raster_bench.py --gpus N --rows 15000 --cols 70000 ...     (starts its own N ranks; also runs as a worker
+                                                                       under an outer torch.distributed.run)
+    python raster_bench.py --rows 15000 --cols 70000 --image-size 512 --stride 64 --batch-size 8 \
+                           --simulate-rank 3 --simulate-world 8 --max-tiles 8     (one GPU takes rank 3's shard of 8)
 
 Every rank pads the raster, takes a contiguous block of 1024-px tile rows (moonsuperresolution_amd.distributed),
 runs getPatch/normalize -> generator -> rebuildTile entirely on its GPU, and (with --gather) all-gathers the finished
@@ -12,10 +15,13 @@ of rank 0, and the share of time outside the generator (tiler + stitcher + host)
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # the tile loop alternates two generator handles (4 streams in all)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -56,13 +62,25 @@ def main():
     ap.add_argument("--tile-size", type=int, default=1024)
     ap.add_argument("--max-tiles", type=int, default=0, help="process at most this many tiles per rank (0 = all)")
     ap.add_argument("--gather", action="store_true", help="all_gather the finished rows on every rank")
+    ap.add_argument("--simulate-rank", type=int, default=-1, help="single process: take this rank's shard ...")
+    ap.add_argument("--simulate-world", type=int, default=0, help="... of this many ranks (no process group)")
+    ap.add_argument("--precision", default="bf16x3")
+    ap.add_argument("--pipeline", type=int, default=2)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # start the N ranks as fresh child processes before this one touches HIP
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        raise SystemExit(subprocess.call(
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+             "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]))
 
     import numpy as np
     import torch
     import torch.distributed as dist
     from moonsuperresolution_amd import DEMSuperResolution, DSRConfig, Generator
-    from moonsuperresolution_amd.distributed import process_map_sharded, shard_tile_rows
+    from moonsuperresolution_amd.distributed import all_gather_rows, shard_tile_rows, tile_rows
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -73,40 +91,58 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     S, s, B, T = args.image_size, args.stride, args.batch_size, args.tile_size
+    t_setup = time.perf_counter()
     img, dem = synthetic_raster(args.rows, args.cols, seed=0)
-    gen = Generator(S, B, variant="gaugan", weights=1234, eps=7, device=local)
-    dsr = DEMSuperResolution(DSRConfig(image_size=S, stride=s, batch_size=B, tile_size=T), model=gen, device=local)
+    gen = Generator(S, B, variant="gaugan", weights=1234, eps=7, device=local, precision=args.precision)
+    dsr = DEMSuperResolution(DSRConfig(image_size=S, stride=s, batch_size=B, tile_size=T), model=gen, device=local,
+                             pipeline=args.pipeline)
     dsr.setImages(img, dem)
+    del img, dem
     dsr.padInputs()
+    t_setup = time.perf_counter() - t_setup
     tiles = dsr.generateTileList()
-    mine = shard_tile_rows(tiles, rank, world)
-    if args.max_tiles:
-        keep = set(mine[:args.max_tiles])
-        tiles = [t for t in tiles if t in keep or t not in mine]
-    counts = {"patches": 0, "calls": 0}
-
-    def run_tile(xx, yy):
-        if args.max_tiles and (xx, yy) not in keep:
-            z = torch.zeros((T, T), device="cuda")
-            return z, z, torch.zeros((T, T), dtype=torch.uint8, device="cuda")
-        out = dsr.processTile(xx, yy)
-        counts["calls"] += len(dsr.last_calls)
-        counts["patches"] += sum(k != (-1, -1) for c in dsr.last_calls for k in c)
-        return out
-
-    # warm-up: one generator call
-    gen.forward_device(torch.zeros((B, S, S, 2), device="cuda"))
+    shard_rank, shard_world = rank, world
+    if args.simulate_world > 0:
+        shard_rank, shard_world = args.simulate_rank, args.simulate_world
+    mine = shard_tile_rows(tiles, shard_rank, shard_world)
+    todo = mine[:args.max_tiles] if args.max_tiles else mine
+    dev = torch.device("cuda", local)
+    rows_all = tile_rows(tiles)
+    my_rows = tile_rows(mine) if mine else []
+    width = len({xx for xx, _ in tiles}) * T
+    # this rank's finished rows stay on the GPU: [rows * T, width] per product
+    prod = [torch.zeros((len(my_rows) * T, width), dtype=torch.float32, device=dev),
+            torch.zeros((len(my_rows) * T, width), dtype=torch.float32, device=dev),
+            torch.zeros((len(my_rows) * T, width), dtype=torch.uint8, device=dev)]
+    patches = calls = 0
+    gen.forward_device(torch.zeros((B, S, S, 2), device="cuda"))     # warm-up: one generator call
+    if todo:
+        dsr.processTile(*todo[0])                                     # and one whole tile (clone handles, streams)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    mean, std, good = process_map_sharded((args.rows, args.cols), T, tiles, run_tile, rank, world, gather=args.gather,
-                                          device=torch.device("cuda", local))
+    for xx, yy in todo:
+        m, sd, g = dsr.processTile(xx, yy)
+        calls += len(dsr.last_calls)
+        patches += sum(k != (-1, -1) for c in dsr.last_calls for k in c)
+        r0 = my_rows.index(yy) * T
+        prod[0][r0:r0 + T, xx:xx + T] = m
+        prod[1][r0:r0 + T, xx:xx + T] = sd
+        prod[2][r0:r0 + T, xx:xx + T] = g
     torch.cuda.synchronize()
+    t_tiles = time.perf_counter() - t0
+    t_gather = 0.0
+    if world > 1 and args.gather:
+        tg = time.perf_counter()
+        prod = [all_gather_rows(t, len(rows_all), T, world) for t in prod]
+        torch.cuda.synchronize()
+        t_gather = time.perf_counter() - tg
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    tot = torch.tensor([counts["patches"], counts["calls"], elapsed], dtype=torch.float64, device="cuda")
+    good_fraction = float(prod[2][:, :args.cols].float().mean()) if prod[2].numel() else 0.0
+    tot = torch.tensor([patches, calls, elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
         mx = tot.clone()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -118,9 +154,15 @@ def main():
             "metric": "raster end-to-end (tiler + generator + stitcher)", "n_gpus": world,
             "raster": [args.rows, args.cols], "image_size": S, "stride": s, "batch_size": B, "tile_size": T,
             "tiles_total": len(tiles), "patches": patches, "generator_calls": calls, "seconds": elapsed,
+            "seconds_tiles_rank0": t_tiles, "seconds_gather_rank0": t_gather,
             "patches_per_s": patches / elapsed,
             "tiles512_per_s": calls * B * (S / 512.0) ** 2 / elapsed,
-            "good_fraction": float(np.mean(good)), "gathered": bool(args.gather),
+            "good_fraction_of_rank0_rows": good_fraction, "gathered": bool(args.gather and world > 1),
+            "canvas": list(dsr.dem_padded_shape), "shard": [shard_rank, shard_world], "tiles_this_rank": len(mine),
+            "tiles_processed_this_rank": len(todo),
+            "setup_seconds_rank0": t_setup, "precision": args.precision, "pipeline": args.pipeline,
+            "device_mem_gib_torch_peak": torch.cuda.max_memory_allocated() / 2 ** 30,
+            "device_mem_gib_generator_handles": args.pipeline * gen.device_bytes() / 2 ** 30,
         }))
     if world > 1:
         dist.destroy_process_group()

@@ -14,17 +14,23 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session", autouse=True)
 def _built_library():
-    """The in-tree library is git-ignored: build it once per session if a fresh checkout lacks it (hipcc
-    cross-compiles for gfx950 without a GPU).  Host-only helpers (CRC-32C, TIFF LZW) live in it too."""
+    """The in-tree library is git-ignored: (re)build it whenever it is missing or was built from other sources than
+    the ones in the tree (content hash in csrc/.build_stamp — a stale .so after a kernel edit would silently test old
+    code).  hipcc cross-compiles for gfx950 without a GPU.  Host-only helpers (CRC-32C, TIFF LZW) live in it too."""
     from moonsuperresolution_amd import _lib
-    if not os.path.exists(_lib.LIB_PATH):
-        _lib.build()
+    if "MSR_LIB" not in os.environ and _lib.is_stale():
+        _lib.build(force=True)
+
+
+def pytest_report_header(config):
+    from moonsuperresolution_amd import _lib
+    return f"libmoonsr_hip: {os.environ.get('MSR_LIB', _lib.LIB_PATH)}"
 
 
 @pytest.fixture(scope="session")
 def hip_lib():
     """The in-tree HIP library; built on demand so a fresh checkout works (hipcc cross-compiles on CPU)."""
     from moonsuperresolution_amd import _lib
-    if not os.path.exists(_lib.LIB_PATH):
-        _lib.build()
+    if "MSR_LIB" not in os.environ and _lib.is_stale():
+        _lib.build(force=True)
     return _lib.load()

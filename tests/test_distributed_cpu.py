@@ -27,8 +27,16 @@ def _worker(rank, world, port, shape, T, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_map_equals_single_process():
-    shape, T = (200, 150), 64      # 4 tile rows x 3 tile columns; rows split 2 / 2
+import pytest
+
+
+@pytest.mark.parametrize("world,shape", [
+    (2, (200, 150)),      # 4 tile rows x 3 tile columns; rows split 2 / 2
+    (3, (250, 100)),      # 4 tile rows on 3 ranks: 2 / 1 / 1 (two short ranks: the gathered blocks are compacted)
+    (3, (300, 70)),       # 5 tile rows on 3 ranks: 2 / 2 / 1
+])
+def test_sharded_map_equals_single_process(world, shape):
+    T = 64
     tiles = [(xx, yy) for yy in range(0, shape[0], T) for xx in range(0, shape[1], T)]
     single = process_map_sharded(shape, T, tiles, lambda x, y: _fake_tile(x, y, T), 0, 1)
     with socket.socket() as s:
@@ -36,14 +44,14 @@ def test_two_rank_sharded_map_equals_single_process():
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, shape, T, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, T, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = dict(q.get(timeout=120) for _ in range(2))
+    results = dict(q.get(timeout=120) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for r in range(2):
+    for r in range(world):
         for a, b in zip(results[r], single):
             assert a.shape == shape and np.array_equal(a, b)
 

@@ -138,24 +138,34 @@ def test_split_bf16_words(ctx):
     assert float(z.abs().max()) == 0.0                                         # the zero border stays zero
 
 
-@pytest.mark.parametrize("tile", [0, 3, 4, 5])
-def test_conv_spade_epilogue_bf16x3_split_output(ctx, tile):
+@pytest.mark.parametrize("tile,B,r,C,shift", [
+    (0, 2, 16, 64, 0), (3, 2, 16, 64, 0), (4, 2, 16, 64, 0), (5, 2, 16, 64, 0),
+    (5, 3, 128, 128, 0),      # 384 ping-pong tiles on 256 persistent workgroups: 1-2 tiles each (the bench regime)
+    (5, 16, 64, 128, 1),      # 512 tiles, x read through the folded 2x up-sample (rb5 spade_1 at S=256, B=16)
+    (4, 3, 32, 256, 1)])      # 192 tiles of the 2-workgroups-per-CU halo form
+def test_conv_spade_epilogue_bf16x3_split_output(ctx, tile, B, r, C, shift):
+    """The SPADE epilogue of the bf16x3 kernels writing split-bf16 words into a zero-bordered tensor, including the
+    persistent ping-pong kernel with more tiles than workgroups (spade.py:19-24 fused into the gamma|beta GEMM)."""
     from moonsuperresolution_amd import ops
-    g = torch.Generator(device="cpu").manual_seed(13)
-    B, r, C = 2, 16, 64
+    g = torch.Generator(device="cpu").manual_seed(13 + B + r)
     h = torch.relu(torch.randn((B, r, r, 128), generator=g)).cuda()
     wg = (torch.randn((3, 3, 128, C), generator=g) / 34).cuda()
     wb = (torch.randn((3, 3, 128, C), generator=g) / 34).cuda()
     bg, bb = torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
-    x = (3 + 2 * torch.randn((B, r, r, C), generator=g)).cuda()
+    x = (3 + 2 * torch.randn((B, r >> shift, r >> shift, C), generator=g)).cuda()
     mean = x.mean((0, 1, 2)).contiguous()
     std = torch.sqrt(x.var((0, 1, 2), unbiased=False) + 1e-5).contiguous()
     w, bias = ops.spade_layout(wg, wb, bg, bb)
     y = ops.conv3x3(ctx, ops.split_bf16(ctx, ops.pad_nhwc(h)), ops.split_bf16(ctx, w), bias, r, epilogue=ops.EPI_SPADE,
-                    aux=x, mean=mean, std=std, out_padded=True, tile=tile, precision="bf16x3", out_split=True)
+                    aux=x, aux_shift=shift, mean=mean, std=std, out_padded=True, tile=tile, precision="bf16x3",
+                    out_split=True)
     hi, lo = unsplit(y)
     val = hi + lo
-    v = ref_conv(h, wg, bg, 1) * ((x.double().cpu() - mean.double().cpu()) / std.double().cpu()) + ref_conv(h, wb, bb, 1)
+    xr = x.double().cpu()
+    if shift:
+        xr = xr.repeat_interleave(2, 1).repeat_interleave(2, 2)
+    torch.set_num_threads(min(16, torch.get_num_threads() if torch.get_num_threads() > 1 else 16))
+    v = ref_conv(h, wg, bg, 1) * ((xr - mean.double().cpu()) / std.double().cpu()) + ref_conv(h, wb, bb, 1)
     v = torch.where(v >= 0, v, 0.2 * v)
     assert rel_linf(val.cpu()[:, 1:-1, 1:-1].numpy(), v.numpy()) <= 5e-5
-    assert float(val.cpu()[:, 0].abs().max()) == 0
+    assert float(val.cpu()[:, 0].abs().max()) == 0 and float(val.cpu()[:, :, -1].abs().max()) == 0

@@ -80,6 +80,39 @@ def test_patch_stats_and_extract_bit_exact(dsr):
     d.close()
 
 
+def test_nan_pixel_and_flat_patch_normalise_like_numpy(dsr):
+    """process_full_tiles.py:307-309 is not guarded: a NaN pixel makes img_patch.min() / .max() NaN (NumPy
+    propagates NaN, fminf would not) so the whole patch normalises to NaN, and a flat patch (max == min) divides
+    0 by 0.  Both stay *valid* (NaN <= no_value is False).  The kernels do exactly the same, bit for bit."""
+    DEMSuperResolution, DSRConfig = dsr
+    img, dem = synthetic_raster(64, 192, 21)
+    img[10, 70] = np.nan                 # patch 1 (x in [64,128)): NaN in the ortho only
+    dem[:, 128:192] = -1234.5            # patch 2: flat DEM
+    d = DEMSuperResolution(DSRConfig(image_size=64, stride=64, batch_size=4, tile_size=128))
+    ox = torch.tensor([0, 64, 128], dtype=torch.int32, device="cuda")
+    oy = torch.zeros(3, dtype=torch.int32, device="cuda")
+    ti, td = torch.from_numpy(img).cuda(), torch.from_numpy(dem).cuda()
+    valid = torch.empty(3, dtype=torch.uint8, device="cuda")
+    mm = torch.empty((3, 4), dtype=torch.float32, device="cuda")
+    assert d._lib.msr_patch_stats(d._h, ti.data_ptr(), td.data_ptr(), 64, 192, ox.data_ptr(), oy.data_ptr(), 3, NOVAL,
+                                  valid.data_ptr(), mm.data_ptr(), None) == 0
+    out = torch.empty((3, 64, 64, 2), dtype=torch.float32, device="cuda")
+    assert d._lib.msr_extract_patches(d._h, ti.data_ptr(), td.data_ptr(), 64, 192, ox.data_ptr(), oy.data_ptr(),
+                                      mm.data_ptr(), 3, out.data_ptr(), None) == 0
+    out, mm = out.cpu().numpy(), mm.cpu().numpy()
+    assert valid.cpu().numpy().tolist() == [1, 1, 1]
+    with np.errstate(all="ignore"):
+        for i in range(3):
+            ok, ip, dp = tiler_ref.get_patch(img, dem, 64 * i, 0, 64, NOVAL)
+            patch, (lo, hi) = tiler_ref.normalize(ip, dp)
+            assert ok
+            assert np.array_equal(out[i], patch.astype(np.float32), equal_nan=True)
+            assert np.array_equal(mm[i], np.array([ip.min(), ip.max(), lo, hi], np.float32), equal_nan=True)
+    assert np.isnan(out[1, :, :, 0]).all() and np.isfinite(out[1, :, :, 1]).all()     # NaN ortho channel, DEM intact
+    assert np.isnan(out[2, :, :, 1]).all() and np.isfinite(out[0]).all()
+    d.close()
+
+
 def test_identity_model_map_bit_exact(dsr):
     """The reference's own known-answer check (process_full_tiles.py:139-143) end to end on the GPU tiler,
     against the NumPy oracle driven by the same (float32) identity model: every output bit-identical."""
@@ -141,6 +174,33 @@ def test_generator_through_tiler_vs_oracle(dsr):
     d1.close()
     d.close()
     gen.close()
+
+
+def test_sharded_map_with_the_real_process_tile(dsr):
+    """distributed.process_map_sharded driven by DEMSuperResolution.processTile (device tensors, HIP generator) for
+    simulated (rank, world) = (0..2, 3) without gather: the three partial maps add up to the single-process map bit
+    for bit — tiles are independent units (process_full_tiles.py:313-325, 431-479)."""
+    from moonsuperresolution_amd import Generator, make_weights
+    from moonsuperresolution_amd.distributed import process_map_sharded, shard_tile_rows
+    DEMSuperResolution, DSRConfig = dsr
+    T = 128
+    img, dem = synthetic_raster(300, 200, 17, hole=(150, 170, 20, 60))       # 3 tile rows x 2 tile columns
+    gen = Generator(64, 4, variant="gaugan_no_kl", weights=make_weights("gaugan_no_kl", 64, seed=3, bias_scale=0.05))
+    d = DEMSuperResolution(DSRConfig(image_size=64, stride=32, batch_size=4, tile_size=T), model=gen)
+    single = d.processMap(img, dem)
+    tiles = d.generateTileList()
+    assert [len(shard_tile_rows(tiles, r, 3)) for r in range(3)] == [2, 2, 2]
+    dev = torch.device("cuda", 0)
+    one = process_map_sharded(dem.shape, T, tiles, d.processTile, 0, 1, device=dev)
+    acc = [np.zeros_like(a) for a in single]
+    for r in range(3):
+        part = process_map_sharded(dem.shape, T, tiles, d.processTile, r, 3, gather=False, device=dev)
+        for a, p in zip(acc, part):
+            a += p
+    for a, b, c in zip(single, one, acc):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+    assert single[2].any()
+    d.close(); gen.close()
 
 
 def test_full_size_stitch_properties(dsr):
