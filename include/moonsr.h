@@ -107,6 +107,21 @@ int msr_patch_stats(msr_handle* h, const float* img_dev, const float* dem_dev, i
 int msr_extract_patches(msr_handle* h, const float* img_dev, const float* dem_dev, int32_t rows, int32_t cols,
                         const int32_t* ox_dev, const int32_t* oy_dev, const float* minmax_dev, int32_t n,
                         float* out_dev, void* stream);
+/* Replaces the batch assembly of processTile (process_full_tiles.py:455-474: skip invalid patches, keep generation
+ * order, cut into calls of `batch`, pad the last call with zero patches keyed (-1,-1)) for one tile, on the device:
+ * a stable compaction of the n candidates of msr_patch_stats by their validity flags.
+ *   cap           capacity of the outputs = ceil(n / batch) * batch (all-valid worst case)
+ *   sel_x / sel_y [cap] int32   origins (padded-canvas coordinates) in generation order, then (-1,-1) padding:
+ *                               what msr_extract_patches takes, `batch` entries per generator call
+ *   sel_minmax    [cap][4]      their {img_min, img_max, dem_min, dem_max}; zeros for padding
+ *   key           [cap][2]      origins relative to (tile_x, tile_y) = the reference's dict keys; (-1,-1) padding
+ *   dmm           [cap][2]      {dem_min, dem_max}: what msr_stitch_tile takes
+ *   meta          [2] int32     {number of valid patches, number of generator calls}
+ * The host reads back only `meta` (8 bytes). */
+int msr_compact_patches(msr_handle* h, const uint8_t* valid_dev, const int32_t* ox_dev, const int32_t* oy_dev,
+                        const float* minmax_dev, int32_t n, int32_t tile_x, int32_t tile_y, int32_t batch, int32_t cap,
+                        int32_t* sel_x_dev, int32_t* sel_y_dev, float* sel_minmax_dev, int32_t* key_dev,
+                        float* dmm_dev, int32_t* meta_dev, void* stream);
 /* Replaces processBatch's "+0.5" and rebuildTile (process_full_tiles.py:340, 363-414) for one tile.
  *   pred_dev    [n, S, S]  generator outputs (last channel), in generation order
  *   key_dev     [n, 2]     int32 (x, y) of each patch relative to the tile origin (padded coords)

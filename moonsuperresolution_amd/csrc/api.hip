@@ -1286,6 +1286,20 @@ int msr_extract_patches(msr_handle* h, const float* img, const float* dem, int32
     return MSR_OK;
 }
 
+int msr_compact_patches(msr_handle* h, const uint8_t* valid, const int32_t* ox, const int32_t* oy, const float* minmax,
+                        int32_t n, int32_t tile_x, int32_t tile_y, int32_t batch, int32_t cap, int32_t* sel_x,
+                        int32_t* sel_y, float* sel_mm, int32_t* key, float* dmm, int32_t* meta, void* stream) {
+    if (!h) return MSR_ERR_INVALID;
+    if (!valid || !ox || !oy || !minmax || !sel_x || !sel_y || !sel_mm || !key || !dmm || !meta || n < 0 || batch < 1)
+        return fail(h, MSR_ERR_INVALID, "msr_compact_patches: bad argument");
+    if (cap < (n + batch - 1) / batch * batch)
+        return fail(h, MSR_ERR_INVALID, "msr_compact_patches: cap %d < ceil(%d / %d) * %d", cap, n, batch, batch);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, launch_compact_patches(valid, ox, oy, minmax, n, tile_x, tile_y, batch, cap, sel_x, sel_y, sel_mm, key, dmm,
+                                     meta, (hipStream_t)stream));
+    return MSR_OK;
+}
+
 int msr_resize_area(msr_handle* h, const float* src, int32_t rows, int32_t cols, int32_t factor, float* dst,
                     int32_t dst_rows, int32_t dst_cols, void* stream) {
     if (!h) return MSR_ERR_INVALID;

@@ -199,6 +199,9 @@ hipError_t launch_patch_stats(const float* img, const float* dem, int rows, int 
                               int n, int S, float no_value, uint8_t* valid, float* minmax, hipStream_t s);
 hipError_t launch_extract_patches(const float* img, const float* dem, int rows, int cols, const int* ox,
                                   const int* oy, const float* minmax, int n, int S, float* out, hipStream_t s);
+hipError_t launch_compact_patches(const uint8_t* valid, const int* ox, const int* oy, const float* minmax, int n,
+                                  int tile_x, int tile_y, int B, int cap, int* sel_x, int* sel_y, float* sel_mm,
+                                  int* key, float* dmm, int* meta, hipStream_t s);
 hipError_t launch_stitch_tile(const float* pred, const int* key, const float* dmm, int n, int S, int T, int stride,
                               float no_value, int as_implemented, const double* window, int* grid_ws,
                               float* mean, float* stdv, uint8_t* good, hipStream_t s);

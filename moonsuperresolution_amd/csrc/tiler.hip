@@ -122,6 +122,72 @@ hipError_t launch_extract_patches(const float* img, const float* dem, int rows, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// compact_patches: the batch assembly of processTile (process_full_tiles.py:455-474) on the device.  The
+// reference's Python loop skips invalid patches, appends the valid ones in generation order (y outer, x inner),
+// cuts them into calls of B and pads the last call with zero patches keyed (-1, -1).  Here one workgroup makes a
+// stable compaction of the tile's n candidates by their validity flags (ballot + popcount per wave, running base
+// per 1024 candidates: order preserved exactly) and fills the tail up to `cap` with the padding entries, so the
+// host only needs the two counts in `meta` = {valid patches, calls} — 8 bytes instead of the flags and a
+// host-side compaction — and can fetch them while the previous tile is still generating.
+//   sel_x / sel_y [cap]   origins in padded-canvas coordinates, (-1,-1) = zero patch (what extract_patches takes)
+//   sel_mm [cap][4]       their {img_min, img_max, dem_min, dem_max}, zeros for padding
+//   key [cap][2]          origins relative to the tile (the reference's dict keys), (-1,-1) for padding
+//   dmm [cap][2]          {dem_min, dem_max} (what stitch_tile takes)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) compact_patches_kernel(const uint8_t* __restrict__ valid,
+                                                               const int* __restrict__ ox, const int* __restrict__ oy,
+                                                               const float* __restrict__ minmax, int n, int tile_x,
+                                                               int tile_y, int B, int cap, int* __restrict__ sel_x,
+                                                               int* __restrict__ sel_y, float* __restrict__ sel_mm,
+                                                               int* __restrict__ key, float* __restrict__ dmm,
+                                                               int* __restrict__ meta) {
+    __shared__ int wsum[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int base = 0;
+    for (int start = 0; start < n; start += 1024) {
+        const int i = start + threadIdx.x;
+        const int v = i < n ? (valid[i] != 0) : 0;
+        const unsigned long long m = __ballot(v);
+        const int pre = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int c = wsum[w];
+            woff += w < wave ? c : 0;
+            tot += c;
+        }
+        if (v) {
+            const int d = base + woff + pre;
+            const int x = ox[i], y = oy[i];
+            sel_x[d] = x; sel_y[d] = y;
+            key[2 * d] = x - tile_x; key[2 * d + 1] = y - tile_y;
+            const float4 mm = *reinterpret_cast<const float4*>(minmax + 4 * (size_t)i);
+            *reinterpret_cast<float4*>(sel_mm + 4 * (size_t)d) = mm;
+            dmm[2 * d] = mm.z; dmm[2 * d + 1] = mm.w;
+        }
+        base += tot;
+        __syncthreads();
+    }
+    for (int d = base + threadIdx.x; d < cap; d += 1024) {
+        sel_x[d] = -1; sel_y[d] = -1;
+        key[2 * d] = -1; key[2 * d + 1] = -1;
+        *reinterpret_cast<float4*>(sel_mm + 4 * (size_t)d) = make_float4(0.f, 0.f, 0.f, 0.f);
+        dmm[2 * d] = 0.f; dmm[2 * d + 1] = 0.f;
+    }
+    if (threadIdx.x == 0) { meta[0] = base; meta[1] = (base + B - 1) / B; }
+}
+
+hipError_t launch_compact_patches(const uint8_t* valid, const int* ox, const int* oy, const float* minmax, int n,
+                                  int tile_x, int tile_y, int B, int cap, int* sel_x, int* sel_y, float* sel_mm,
+                                  int* key, float* dmm, int* meta, hipStream_t s) {
+    compact_patches_kernel<<<1, 1024, 0, s>>>(valid, ox, oy, minmax, n, tile_x, tile_y, B, cap, sel_x, sel_y, sel_mm,
+                                              key, dmm, meta);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // stitch_tile: rebuildTile (process_full_tiles.py:363-414) as a GATHER: one thread per output pixel of the
 // cropped [T,T] tile walks the <= ((S-2p)/s)^2 patches covering it in generation order (y outer, x inner —
 // the insertion order of the reference's dict) and applies the weighted incremental update in registers.
