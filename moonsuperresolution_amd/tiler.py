@@ -10,9 +10,11 @@ What moves to the GPU (libmoonsr_hip.so, csrc/tiler.hip):
   getPatch + normalize     -> msr_patch_stats + msr_extract_patches   (validity, min/max, [-0.5,0.5] scaling)
   processBatch             -> Generator.forward_device (patches never leave HBM) or any host callable
   rebuildTile              -> msr_stitch_tile (gather-form weighted incremental mean / variance, bit-exact)
-The only host synchronisation per tile is the read-back of the patch validity flags, which decide the batch
-composition exactly as the reference's Python loop does (invalid patches are skipped, the last batch is
+  batch assembly           -> msr_compact_patches (stable device-side compaction of the valid patches)
+Batch composition is exactly the reference's Python loop (invalid patches are skipped, the last batch is
 zero-padded: process_full_tiles.py:455-474) — SPADE's batch statistics make that composition part of the result.
+The host needs only the two counts (valid patches, calls) of a tile, 8 bytes fetched through pinned memory while
+the previous tile is still generating (iterTiles), so the generator stream never drains between tiles.
 """
 from __future__ import annotations
 
@@ -91,6 +93,9 @@ class DEMSuperResolution:
         self.pipeline = max(1, int(pipeline))        # generator handles / streams the calls of a tile alternate over
         self._gens = None
         self._pstreams = None
+        self._prep_stream = None
+        self._last = (None, 0, 0)
+        self._last_calls = None
         S, s = self.image_size, self.stride
         if S < 64 or S & (S - 1):
             # narrower than the reference (any size): the generator's six 2x up-samplings from S/64 and the conv
@@ -214,6 +219,7 @@ class DEMSuperResolution:
             h, w = self.dem_shape
             self.dem_padded[S - s:S - s + h, S - s:S - s + w] = torch.from_numpy(self.dem).to(self.device)
             self.img_padded[S - s:S - s + h, S - s:S - s + w] = torch.from_numpy(self.img).to(self.device)
+            torch.cuda.current_stream(self.device).synchronize()   # the tile loop reads the canvases on other streams
         self.dem_padded_shape = tuple(self.dem_padded.shape)
         self.img_padded_shape = tuple(self.img_padded.shape)
         self.dem = None
@@ -242,41 +248,69 @@ class DEMSuperResolution:
         xs = np.arange(px, px + span, self.stride, dtype=np.int32)
         return np.stack([np.tile(xs, len(ys)), np.repeat(ys, len(xs))], axis=1)
 
-    def processTile(self, px: int, py: int):
-        """process_full_tiles.py:431-479 without the disk write: returns (mean, std, good) device tensors [T,T].
-
-        Also records ``self.last_calls``: the patch keys of every generator call of the tile (with (-1,-1)
-        padding entries), i.e. the batch composition the reference would have produced."""
+    # -- one tile = prepare (validity, min/max, device-side batch assembly) -> generate -> stitch -------------------
+    def _prepare_tile(self, px: int, py: int):
+        """Asynchronous first half of processTile on the handle's preparation stream: getPatch's validity test and
+        normalize's reductions for every patch of the tile (msr_patch_stats), then the batch assembly of
+        process_full_tiles.py:455-474 on the device (msr_compact_patches).  The host gets back two integers
+        {valid patches, calls} through pinned memory, behind an event — it fetches them while the GPU is still busy
+        with the previous tile (processTiles), so no flag array crosses PCIe and no host-side compaction exists."""
         S, s, B, T = self.image_size, self.stride, self.batch_size, self.tile_size
         lib, h, dev = self._lib, self._h, self.device
-        with torch.cuda.device(dev):
-            rows, cols = self.dem_padded_shape
-            org = self.patchOrigins(px, py)
-            n = org.shape[0]
-            ox = torch.from_numpy(np.ascontiguousarray(org[:, 0])).to(dev)
-            oy = torch.from_numpy(np.ascontiguousarray(org[:, 1])).to(dev)
+        if self._prep_stream is None:
+            self._prep_stream = torch.cuda.Stream(dev)
+        rows, cols = self.dem_padded_shape
+        span = T + S - s
+        st = {"px": px, "py": py}
+        with torch.cuda.device(dev), torch.cuda.stream(self._prep_stream):
+            xs = torch.arange(px, px + span, s, dtype=torch.int32, device=dev)
+            ys = torch.arange(py, py + span, s, dtype=torch.int32, device=dev)
+            ox = xs.repeat(ys.numel())                      # generation order: y outer, x inner (:453-454)
+            oy = ys.repeat_interleave(xs.numel())
+            n = int(xs.numel() * ys.numel())
+            cap = max(B, (n + B - 1) // B * B)
             valid = torch.empty(n, dtype=torch.uint8, device=dev)
             minmax = torch.empty((n, 4), dtype=torch.float32, device=dev)
+            sx = torch.empty(cap, dtype=torch.int32, device=dev)
+            sy = torch.empty(cap, dtype=torch.int32, device=dev)
+            mm_sel = torch.empty((cap, 4), dtype=torch.float32, device=dev)
+            keys = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+            dmm = torch.empty((cap, 2), dtype=torch.float32, device=dev)
+            meta = torch.empty(2, dtype=torch.int32, device=dev)
+            stream = self._prep_stream.cuda_stream
             rc = lib.msr_patch_stats(h, self.img_padded.data_ptr(), self.dem_padded.data_ptr(), rows, cols,
                                      ox.data_ptr(), oy.data_ptr(), n, self.no_value, valid.data_ptr(),
-                                     minmax.data_ptr(), self._stream())
+                                     minmax.data_ptr(), stream)
             _lib.raise_for(lib, h, rc, "msr_patch_stats")
-            keep = np.flatnonzero(valid.cpu().numpy())          # the one host sync of the tile
-            nv = int(keep.size)
-            ncall = (nv + B - 1) // B
-            total = ncall * B
-            # compacted origins in generation order, padded with (-1,-1) up to a whole number of calls
-            sel = np.full((total, 2), -1, np.int32)
-            sel[:nv] = org[keep]
-            keys = sel.copy()
-            keys[:nv, 0] -= px
-            keys[:nv, 1] -= py
-            self.last_calls = [[tuple(int(v) for v in k) for k in keys[c * B:(c + 1) * B]] for c in range(ncall)]
-            mm_sel = torch.zeros((total, 4), dtype=torch.float32, device=dev)
-            if nv:
-                mm_sel[:nv] = minmax[torch.from_numpy(keep).to(dev)]
-            sx = torch.from_numpy(np.ascontiguousarray(sel[:, 0])).to(dev)
-            sy = torch.from_numpy(np.ascontiguousarray(sel[:, 1])).to(dev)
+            rc = lib.msr_compact_patches(h, valid.data_ptr(), ox.data_ptr(), oy.data_ptr(), minmax.data_ptr(), n, px, py,
+                                         B, cap, sx.data_ptr(), sy.data_ptr(), mm_sel.data_ptr(), keys.data_ptr(),
+                                         dmm.data_ptr(), meta.data_ptr(), stream)
+            _lib.raise_for(lib, h, rc, "msr_compact_patches")
+            meta_host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            meta_host.copy_(meta, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._prep_stream)
+        st.update(n=n, cap=cap, sx=sx, sy=sy, mm_sel=mm_sel, keys=keys, dmm=dmm, meta=meta, meta_host=meta_host, event=ev,
+                  keep=(ox, oy, valid, minmax))
+        return st
+
+    def _generate_tile(self, st):
+        """Second half of processTile: the tile's generator calls (batches cut from the compacted origins, the last
+        one zero-padded) and the stitcher, all on the current stream / the pipeline streams."""
+        S, B = self.image_size, self.batch_size
+        lib, h, dev = self._lib, self._h, self.device
+        rows, cols = self.dem_padded_shape
+        st["event"].synchronize()                     # 8 bytes; the GPU keeps working on what is already queued
+        nv, ncall = (int(v) for v in st["meta_host"].tolist())
+        total = ncall * B
+        sx, sy, mm_sel = st["sx"], st["sy"], st["mm_sel"]
+        self._last = (st["keys"], nv, ncall)
+        self._last_calls = None
+        with torch.cuda.device(dev):
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_event(st["event"])
+            for t in (sx, sy, mm_sel, st["keys"], st["dmm"]):
+                t.record_stream(cur)
             preds = torch.empty((max(total, 1), S, S), dtype=torch.float32, device=dev)
             if self._gen is not None:
                 # The calls of a tile are independent batches: alternate them over `pipeline` generator handles, each
@@ -288,10 +322,9 @@ class DEMSuperResolution:
                     if g.weights_version != self._gen.weights_version:
                         g.load(self._gen._weights)
                         g.weights_version = self._gen.weights_version
-                cur = torch.cuda.current_stream(dev)
                 batches = [torch.empty((B, S, S, 2), dtype=torch.float32, device=dev) for _ in self._gens]
-                for st in self._pstreams:
-                    st.wait_stream(cur)
+                for ps in self._pstreams:
+                    ps.wait_stream(cur)
                 for c in range(ncall):
                     k = c % len(self._gens)
                     with torch.cuda.stream(self._pstreams[k]):
@@ -300,10 +333,10 @@ class DEMSuperResolution:
                                                      mm_sel[c * B:].data_ptr(), B, batches[k].data_ptr(), self._stream())
                         _lib.raise_for(lib, h, rc, "msr_extract_patches")
                         self._gens[k].forward_device(batches[k], out=preds[c * B:(c + 1) * B].unsqueeze(-1))
-                for st in self._pstreams:
-                    cur.wait_stream(st)
+                for ps in self._pstreams:
+                    cur.wait_stream(ps)
                     for t in batches + [preds, sx, sy, mm_sel]:
-                        t.record_stream(st)
+                        t.record_stream(ps)
             else:
                 batch = torch.empty((B, S, S, 2), dtype=torch.float32, device=dev)
                 for c in range(ncall):
@@ -313,9 +346,28 @@ class DEMSuperResolution:
                     _lib.raise_for(lib, h, rc, "msr_extract_patches")
                     out = np.array(self.model(batch.cpu().numpy(), training=False))[:, :, :, -1]
                     preds[c * B:(c + 1) * B] = torch.from_numpy(np.ascontiguousarray(out, dtype=np.float32)).to(dev)
-            key_d = torch.from_numpy(np.ascontiguousarray(keys[:nv])).to(dev) if nv else torch.zeros((1, 2), dtype=torch.int32, device=dev)
-            dmm = mm_sel[:max(nv, 1), 2:4].contiguous()
-            return self.rebuildTile(preds, key_d, dmm, nv)
+            return self.rebuildTile(preds, st["keys"], st["dmm"], nv)
+
+    def processTile(self, px: int, py: int):
+        """process_full_tiles.py:431-479 without the disk write: returns (mean, std, good) device tensors [T,T].
+
+        ``self.last_calls`` gives the patch keys of every generator call of the tile (with (-1,-1) padding
+        entries), i.e. the batch composition the reference would have produced; ``self.last_counts`` the
+        (valid patches, calls) pair without a read-back."""
+        return self._generate_tile(self._prepare_tile(px, py))
+
+    @property
+    def last_counts(self) -> Tuple[int, int]:
+        return self._last[1], self._last[2]
+
+    @property
+    def last_calls(self):
+        if self._last_calls is None:
+            keys, nv, ncall = self._last
+            B = self.batch_size
+            k = keys[:ncall * B].cpu().numpy()
+            self._last_calls = [[tuple(int(v) for v in kk) for kk in k[c * B:(c + 1) * B]] for c in range(ncall)]
+        return self._last_calls
 
     def rebuildTile(self, preds: torch.Tensor, keys: torch.Tensor, dem_minmax: torch.Tensor, n: Optional[int] = None):
         """process_full_tiles.py:363-414 on the GPU.  preds [n,S,S] raw generator outputs (the +0.5 of :340 is
@@ -333,12 +385,44 @@ class DEMSuperResolution:
         return mean, std, good
 
     # ------------------------------------------------------------------------------------------------
+    def iterTiles(self, tiles: Sequence[Tuple[int, int]]):
+        """Yield ((xx, yy), (mean, std, good) device tensors) for every tile, software-pipelined: the preparation of
+        tile t+1 (validity, min/max, device-side batch assembly — a few small kernels on their own stream) is queued
+        before the host waits for tile t's two counts, so that wait ends while the GPU is still generating tile t-1
+        and the generator stream never drains between tiles (the reference is serial: process_full_tiles.py:453-478)."""
+        tiles = list(tiles)
+        if not tiles:
+            return
+        nxt = self._prepare_tile(*tiles[0])
+        for i, (xx, yy) in enumerate(tiles):
+            st = nxt
+            nxt = self._prepare_tile(*tiles[i + 1]) if i + 1 < len(tiles) else None
+            yield (xx, yy), self._generate_tile(st)
+
     def processTiles(self, tiles: Sequence[Tuple[int, int]]):
-        """Process a list of tiles (this rank's shard); returns {(xx,yy): (mean, std, good)} of host arrays."""
+        """Process a list of tiles (this rank's shard); returns {(xx,yy): (mean, std, good)} of host arrays.
+        Results come back through pinned buffers with asynchronous copies retired two tiles late, so the device-to-host
+        transfer of tile t never stalls the launches of tile t+1."""
         out = {}
-        for xx, yy in tiles:
-            m, s, g = self.processTile(xx, yy)
-            out[(xx, yy)] = (m.cpu().numpy(), s.cpu().numpy(), g.cpu().numpy())
+        pending = []
+
+        def retire(item):
+            key, ev, bufs = item
+            ev.synchronize()
+            out[key] = tuple(np.array(b.numpy()) for b in bufs)
+
+        for key, (m, s, g) in self.iterTiles(tiles):
+            with torch.cuda.device(self.device):
+                bufs = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (m, s, g)]
+                for b, t in zip(bufs, (m, s, g)):
+                    b.copy_(t, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+            pending.append((key, ev, bufs, (m, s, g)))
+            while len(pending) > 2:
+                retire(pending.pop(0)[:3])
+        for item in pending:
+            retire(item[:3])
         return out
 
     def rebuildMap(self, tiles: dict):

@@ -122,10 +122,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for xx, yy in todo:
-        m, sd, g = dsr.processTile(xx, yy)
-        calls += len(dsr.last_calls)
-        patches += sum(k != (-1, -1) for c in dsr.last_calls for k in c)
+    for (xx, yy), (m, sd, g) in dsr.iterTiles(todo):
+        nv, nc = dsr.last_counts
+        calls += nc
+        patches += nv
         r0 = my_rows.index(yy) * T
         prod[0][r0:r0 + T, xx:xx + T] = m
         prod[1][r0:r0 + T, xx:xx + T] = sd
