@@ -53,9 +53,11 @@ WORKLOADS = {
 }
 # MI355X_MICROARCH.md: dense MFMA peaks.  For bf16x3 every algorithmic product costs three bf16 MFMA products, so
 # the algorithmic ceiling is a third of the bf16 peak; `achieved` stays ALGORITHMIC FLOP/s in every mode.
-PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0}
-MFMA_PER_PRODUCT = {"fp32": 1, "bf16x3": 3}
-DTYPE = {"fp32": "f32", "bf16x3": "bf16x3 (f32 in/out/accumulate)"}
+PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16x3_gbf16": 2500.0}
+# MFMA products per algorithmic product; the opt-in mode runs 2 in the gamma|beta convs (half of the FLOPs), 3 elsewhere
+MFMA_PER_PRODUCT = {"fp32": 1, "bf16x3": 3, "bf16x3_gbf16": 2.5}
+DTYPE = {"fp32": "f32", "bf16x3": "bf16x3 (f32 in/out/accumulate)",
+         "bf16x3_gbf16": "bf16x3, gamma|beta convs f16x2 (opt-in; f32 in/out/accumulate; 2-5e-4 rel L-inf, inside the 1e-3 bar)"}
 
 
 def host_threads() -> int:
@@ -305,10 +307,10 @@ def run_workload(args, D: Dist, workload: str, precision: str, with_cpu: bool, w
             k = MFMA_PER_PRODUCT[precision]
             rl["mfma_executed_tflops"] = k * ach
             rl["frac_of_executed_mfma_peak"] = k * ach / peak
-            rl["note"] = (f"frac = algorithmic FLOP/s over the dense bf16 MFMA peak; {precision} issues {k} bf16 MFMA "
-                          "products per algorithmic product, so the matrix pipe executes that multiple of `achieved` "
-                          "(frac_of_executed_mfma_peak) and frac is capped at 1/" + str(k))
-        pmc = pmc_traffic(workload + ("" if precision == "fp32" else "_" + precision))
+            rl["note"] = (f"frac = algorithmic FLOP/s over the dense bf16/f16 MFMA peak; {precision} issues {k} MFMA "
+                          "products per algorithmic product (average over the conv FLOPs), so the matrix pipe executes "
+                          "that multiple of `achieved` (frac_of_executed_mfma_peak) and frac is capped at 1/" + str(k))
+        pmc = pmc_traffic(workload + ("" if precision == "fp32" else "_bf16x3"))
         if pmc and "conv_igemm" in pmc[0]:
             rl["traffic"] = pmc[0]["conv_igemm"]["hbm_bytes_per_forward"] / (conv["launches"] / args.steps)
             rl["traffic_source"] = "profiles/" + pmc[1]
@@ -373,8 +375,8 @@ def main():
                        with_b1=solo and not args.no_also)
     if solo and not args.no_also:
         also = {}
-        for wl, prec in (("spade256", "bf16x3"), ("spade256", "fp32"), ("spade512", "fp32")):
-            if (wl, prec) == (args.workload, args.precision) or (wl, prec) == ("spade512", "fp32"):
+        for wl, prec in (("spade512", "bf16x3_gbf16"), ("spade256", "bf16x3"), ("spade256", "fp32")):
+            if (wl, prec) == (args.workload, args.precision):
                 continue
             r = run_workload(args, D, wl, prec, with_cpu=False, with_b1=False)
             also[f"{wl}_{prec}"] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config",

@@ -53,12 +53,21 @@ typedef struct {
     int32_t flags;       /* MSR_FLAG_* */
 } msr_config;
 
-/* Conv arithmetic.  Default (0): exact fp32 on v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak).
- * MSR_FLAG_BF16X3: 3-term split-bf16 products (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi) on v_mfma_f32_32x32x16_bf16
- * with fp32 accumulation: per-product error <= ~3*2^-18, all other arithmetic (moments, normalisation, epilogues,
- * dense, head) stays fp32.  Inputs, outputs and weights of the C ABI are fp32 either way.  MSR_PIX2PIX ignores the
- * flag and always computes on the fp32 MFMA. */
+/* Conv arithmetic (msr_config.flags).  Inputs, outputs and weights of the C ABI are fp32 in every mode, and so is all
+ * other arithmetic (moments, normalisation, epilogues, dense layers, head); only the conv products differ:
+ *   0                 exact fp32 on v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak).  NOTE: 0 is the C-ABI default; the Python
+ *                     host (moonsuperresolution_amd.Generator) defaults to MSR_FLAG_BF16X3, which is ~3.4x faster.
+ *   MSR_FLAG_BF16X3   3-term split-bf16 products (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi) with fp32 accumulation, on
+ *                     v_mfma_f32_16x16x32_bf16 in the LDS-halo kernels (the r >= 16 layers, 91 % of the FLOPs) and on
+ *                     v_mfma_f32_32x32x16_bf16 in the small-tile ones: per-product error <= ~3*2^-18.
+ *   MSR_FLAG_BF16X3 | MSR_FLAG_GB_F16X2   opt-in: as BF16X3, but the SPADE gamma|beta convs (spade.py:19-20, half of
+ *                     the FLOPs) of the layers that run the persistent ping-pong kernel use 2-term fp16 products
+ *                     (activation split in two fp16 halves, weight rounded to ONE fp16; v_mfma_f32_16x16x32_f16):
+ *                     per-product error <= 2^-12, measured 2-5e-4 relative L-inf end to end (inside north_star's 1e-3,
+ *                     with a 2-4x margin instead of 50x; tests/test_gpu_baseline_configs.py states the bound).
+ * MSR_PIX2PIX ignores the flags and always computes on the fp32 MFMA. */
 #define MSR_FLAG_BF16X3 1
+#define MSR_FLAG_GB_F16X2 2
 
 typedef struct msr_handle msr_handle;
 
@@ -193,7 +202,9 @@ int msr_op_conv3x3(msr_handle* h, const float* in_dev, const float* wt_dev, cons
                    const float* aux_dev, int32_t aux_shift, const float* mean_dev, const float* std_dev,
                    int32_t out_padded, int32_t tile, void* stream);
 /* The same with in_dev / wt_dev holding split-bf16 words (msr_op_split_bf16) and the bf16x3 arithmetic;
- * out_split != 0 (SPADE epilogue only) writes split-bf16 words too. */
+ * out_split != 0 (SPADE epilogue only) writes split-bf16 words too.  tile: (0 = 128x128 | 1 = 64x64 | 3, 4 = LDS-halo
+ * forms | 5 = persistent ping-pong) + 0x40 (weights in MFMA-fragment order, tiles 0 / 1) + 0x80 (tile 5, SPADE epilogue
+ * only: in_dev / wt_dev hold split-FP16 words and the products are the 2-term form of MSR_FLAG_GB_F16X2) + 256 * ksplit. */
 int msr_op_conv3x3_bf16x3(msr_handle* h, const float* in_dev, const float* wt_dev, const float* bias_dev,
                           float* out_dev, int32_t B, int32_t rout, int32_t Cin, int32_t N, int32_t stride,
                           int32_t epilogue, const float* aux_dev, int32_t aux_shift, const float* mean_dev,

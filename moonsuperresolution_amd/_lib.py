@@ -17,7 +17,8 @@ MSR_ERR_STATE = -3
 MSR_ERR_NOMEM = -4
 
 VARIANT_IDS = {"gaugan": 0, "gaugan_no_kl": 1, "cnn": 2, "pix2pix": 3}
-PRECISION_FLAGS = {"fp32": 0, "bf16x3": 1}   # msr_config.flags (MSR_FLAG_BF16X3)
+# msr_config.flags: MSR_FLAG_BF16X3 = 1, MSR_FLAG_GB_F16X2 = 2 (opt-in 2-term fp16 products in the gamma|beta convs)
+PRECISION_FLAGS = {"fp32": 0, "bf16x3": 1, "bf16x3_gbf16": 3}
 
 
 class MsrConfig(C.Structure):

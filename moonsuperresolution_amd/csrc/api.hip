@@ -59,6 +59,7 @@ struct msr_handle {
     msr_config cfg{};
     int S = 0, B = 0, L = 0, variant = 0;
     int prec = 0;                                // PREC_F32 or PREC_BF16X3 (cfg.flags & MSR_FLAG_BF16X3)
+    bool gb_f16x2 = false;                       // MSR_FLAG_GB_F16X2: 2-term fp16 products in the gamma|beta convs
     std::string err;
     std::vector<WeightSpec> specs;
     std::map<std::string, int> spec_index;
@@ -242,11 +243,17 @@ void hwio_to_tap_oc_ic(const float* src, float* dst, int taps, int cin, int cout
 //   [tap][chunk of 32 k][n-tile of 32][kg][hi|lo][lane = 32*h + j][8 bf16],  value = W[tap][32*nt + j][32*cc + 16*kg + 8*h + e]
 // `host` is the kernel layout [taps][N][Cin].
 int upload_conv_weight(msr_handle* h, const std::string& key, const float* host, size_t floats, int taps, int N,
-                       int Cin, bool frag) {
+                       int Cin, bool frag, bool f16 = false) {
     if (h->prec != PREC_BF16X3) return upload(h, key, host, floats);
     if (N % 32 || Cin % 32 || (size_t)taps * N * Cin != floats)
         return fail(h, MSR_ERR_INVALID, "%s: bf16x3 needs Cin and Cout multiples of 32", key.c_str());
     std::vector<float> t(floats);
+    if (f16) {
+        // split-fp16 image of [tap][N][Cin] (PREC_F16X2 reads only the hi half of every chunk)
+        for (size_t i = 0; i + 3 < floats; i += 4)
+            msr_store_split4_f16(t.data() + (i & ~(size_t)31), (int)(i & 31), host[i], host[i + 1], host[i + 2], host[i + 3]);
+        return upload(h, key, t.data(), floats);
+    }
     if (!frag) {
         // split-bf16 image of [tap][N][Cin]: every 32 consecutive k become [32 hi | 32 lo]
         for (size_t i = 0; i + 3 < floats; i += 4)
@@ -279,14 +286,23 @@ struct ConvVariant { int tile; int wt_frag; };
 ConvVariant pick_conv_variant(int B, int rout, int N, int stride, int epi, int prec, int cin);
 
 // Output resolution of the conv a weight belongs to ("enc.ds3.kernel" -> S>>3, "gen.rb4...." -> sw<<3).
+bool weight_conv_shape(msr_handle* h, const std::string& name, int* rout, int* stride) {
+    int i = 0;
+    *stride = 1;
+    if (std::sscanf(name.c_str(), "enc.ds%d.", &i) == 1) { *rout = h->S >> i; *stride = 2; return true; }
+    if (std::sscanf(name.c_str(), "gen.rb%d.", &i) == 1) { *rout = (h->S / 64) << (i - 1); return true; }
+    return false;
+}
 bool weight_uses_frag(msr_handle* h, const std::string& name, int N, int epi, int cin) {
     if (h->prec != PREC_BF16X3) return false;
     int rout = 0, stride = 1;
-    int i = 0;
-    if (std::sscanf(name.c_str(), "enc.ds%d.", &i) == 1) { rout = h->S >> i; stride = 2; }
-    else if (std::sscanf(name.c_str(), "gen.rb%d.", &i) == 1) rout = (h->S / 64) << (i - 1);
-    else return false;
+    if (!weight_conv_shape(h, name, &rout, &stride)) return false;
     return pick_conv_variant(h->B, rout, N, stride, epi, h->prec, cin).wt_frag != 0;
+}
+// MSR_FLAG_GB_F16X2: the gamma|beta convs that run the persistent ping-pong kernel take 2-term fp16 products; the
+// planner (conv precision, format of the mask embedding that feeds them) and the weight upload both ask this.
+bool gb_uses_f16x2(msr_handle* h, int rout, int N, int cin) {
+    return h->gb_f16x2 && pick_conv_variant(h->B, rout, N, 1, EPI_SPADE, PREC_BF16X3, cin).tile == TILE_256x128_PP;
 }
 
 }  // namespace
@@ -360,7 +376,10 @@ int msr_create(const msr_config* cfg, msr_handle** out) {
     h->cfg = *cfg;
     h->S = S; h->B = B; h->L = cfg->latent_dim; h->variant = cfg->variant;
     h->prec = (cfg->flags & MSR_FLAG_BF16X3) ? PREC_BF16X3 : PREC_F32;
-    if (cfg->variant == MSR_PIX2PIX) h->prec = PREC_F32;   // the 11.9-GFLOP parity config runs on the fp32 MFMA
+    h->gb_f16x2 = h->prec == PREC_BF16X3 && (cfg->flags & MSR_FLAG_GB_F16X2);
+    if ((cfg->flags & MSR_FLAG_GB_F16X2) && !(cfg->flags & MSR_FLAG_BF16X3))
+        return fail(nullptr, MSR_ERR_INVALID, "MSR_FLAG_GB_F16X2 needs MSR_FLAG_BF16X3");
+    if (cfg->variant == MSR_PIX2PIX) { h->prec = PREC_F32; h->gb_f16x2 = false; }   // the parity config runs on the fp32 MFMA
     build_specs(h.get());
     *out = h.release();
     return MSR_OK;
@@ -518,8 +537,10 @@ int msr_load_weight(msr_handle* h, const char* name_c, const float* host, const 
             std::vector<float>& img = h->host_small[base + ".gb.kernel"];
             img.resize((size_t)9 * 2 * C * cin);
             hwio_to_tap_oc_ic(host, img.data(), 9, cin, C, 2 * C, rowmap.data());
+            int rout = 0, stride = 1;
+            weight_conv_shape(h, name, &rout, &stride);
             rc = upload_conv_weight(h, base + ".gb.kernel", img.data(), img.size(), 9, 2 * C, cin,
-                                    weight_uses_frag(h, name, 2 * C, EPI_SPADE, cin));
+                                    weight_uses_frag(h, name, 2 * C, EPI_SPADE, cin), gb_uses_f16x2(h, rout, 2 * C, cin));
         }
     } else if (ends_with(name, ".conv_gamma.bias") || ends_with(name, ".conv_beta.bias")) {
         const bool is_beta = ends_with(name, ".conv_beta.bias");
@@ -741,7 +762,8 @@ int plan_spade(msr_handle* h) {
             p.ay = 1; p.cy = -1; p.lim = r; p.f = S / r; p.o = (S / r) / 2;
             p.out_px = 128; p.out_py = hb.py(); p.out_pb = hb.pb(); p.out_off = hb.interior();
             p.act = 1; p.slope = 0.f;
-            p.out_split = h->prec == PREC_BF16X3;
+            const bool f16x2 = gb_uses_f16x2(h, r, 2 * C, 128);
+            p.out_split = f16x2 ? 2 : (h->prec == PREC_BF16X3 ? 1 : 0);
             em.flops = 2.0 * B * r * r * 18.0 * 128;
             em.on_aux = true;
             em.aux_group = i <= 4 ? 0 : 1;        // rb1-4 embeds are small and done early; rb5-6 carry the bytes
@@ -751,6 +773,7 @@ int plan_spade(msr_handle* h) {
             snprintf(k, sizeof k, "gen.rb%d.spade_%d.gb.kernel", i, j); const float* gbw = need(k);
             snprintf(k, sizeof k, "gen.rb%d.spade_%d.gb.bias", i, j); const float* gbb = need(k);
             Op gb = conv_op(hb, gbw, gbb, B, r, 2 * C, 1, EPI_SPADE, h->prec);
+            if (f16x2) gb.conv.prec = PREC_F16X2;     // same tile, same layouts; fp16 encodings, 2 MFMAs per product
             set_out_padded(gb.conv, ab);
             set_aux_dense(gb.conv, x, rx, C, xshift);
             gb.conv.mean = mean; gb.conv.stdv = stdv;
@@ -1147,6 +1170,7 @@ static int op_conv_impl(msr_handle* h, const float* in_dev, const float* wt_dev,
     op.conv.mean = mean_dev; op.conv.stdv = std_dev;
     if (tile >= 0) {
         op.tile = tile & 0x3F;
+        if (tile & 0x80) op.conv.prec = PREC_F16X2;            // operands are split-fp16 words (ping-pong tile only)
         op.conv.wt_frag = (tile & 0x40) ? 1 : 0;
         op.conv.ksplit = (tile >> 8) > 0 ? (tile >> 8) : 1;    // explicit tile: explicit split (default none)
     }

@@ -23,6 +23,7 @@ namespace msr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // K-step = BKC channels of one tap; LDS rows are BKC + 4 floats.  Both pitches (36 and 20 floats) put the 16
 // lanes of a ds_read_b128 group on 16 distinct 16-byte slots, i.e. the fragment reads are conflict-free.
@@ -1060,7 +1061,10 @@ conv_igemm_bf16x3_halo(const ConvParams p, const TileGeom g) {
 // groups (phases 2t, 2t+1); that buffer was last read in R(t-1) (phases 2t-2, 2t-1) and is next read in R(t+1)
 // (phases 2t+2, 2t+3).  The halo of chunk c+1 goes to Ah[(c+1)&1] on tap 7 of chunk c.
 // ------------------------------------------------------------------------------------------------------
-template <int EPI>
+// F16X2 = true is the opt-in 2-term form for the gamma|beta convs (kernels.h PREC_F16X2): operands are split-fp16
+// words, the weight's lo half is neither read from LDS nor multiplied: 32 MFMAs and 12 ds_read_b128 per K-step
+// instead of 48 and 16.
+template <int EPI, bool F16X2>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
     constexpr int NTHR = 512, BN = 128, BKC = 32, BKP = 40;
@@ -1203,12 +1207,20 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
             ah[i] = *reinterpret_cast<const bf16x8*>(a_ + a_frag[i]);                            \
             al[i] = *reinterpret_cast<const bf16x8*>(a_ + a_frag[i] + 16);                       \
             bh[i] = *reinterpret_cast<const bf16x8*>(b_ + b_frag[i]);                            \
-            bl[i] = *reinterpret_cast<const bf16x8*>(b_ + b_frag[i] + 16);                       \
+            if constexpr (!F16X2) bl[i] = *reinterpret_cast<const bf16x8*>(b_ + b_frag[i] + 16); \
         }                                                                                        \
     }
 // M(T): matrix segment, registers only (weights as the row operand: D[channel][pixel])
+#define MSR_F16(v) __builtin_bit_cast(f16x8, v)
 #define MSR_M()                                                                                  \
-    {                                                                                            \
+    if constexpr (F16X2) {                                                                       \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                          \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                        \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(MSR_F16(bh[j]), MSR_F16(al[i]), acc[i][j], 0, 0, 0); \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                        \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(MSR_F16(bh[j]), MSR_F16(ah[i]), acc[i][j], 0, 0, 0); \
+        }                                                                                        \
+    } else {                                                                                     \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                          \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                        \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0); \
@@ -1320,6 +1332,7 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
 #undef MSR_WRITE_B
 #undef MSR_R
 #undef MSR_M
+#undef MSR_F16
 #undef MSR_STEP
 #undef MSR_PAIR
 }
@@ -1448,11 +1461,11 @@ static constexpr size_t PP_LDS = (size_t)(2 * 324 + 2 * 128) * 40 * sizeof(float
 
 static hipError_t set_attr_halo() {
     hipError_t e;
-#define MSR_SETPP(EPI)                                                                                        \
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_pp<EPI>),                    \
+#define MSR_SETPP(EPI, F16)                                                                                   \
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_pp<EPI, F16>),               \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_LDS)) != hipSuccess)      \
         return e;
-    MSR_SETPP(EPI_BIAS) MSR_SETPP(EPI_RES) MSR_SETPP(EPI_SPADE)
+    MSR_SETPP(EPI_BIAS, false) MSR_SETPP(EPI_RES, false) MSR_SETPP(EPI_SPADE, false) MSR_SETPP(EPI_SPADE, true)
 #undef MSR_SETPP
 #define MSR_SET(EPI)                                                                                          \
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_halo<EPI, 0>),               \
@@ -1708,16 +1721,22 @@ static hipError_t launch_pp(const ConvParams& p, int epi, hipStream_t s) {
         if (n_cu < 8) n_cu = 8;
     }
     const int grid = g.tiles_mn < n_cu ? ((g.tiles_mn + 7) & ~7) : n_cu;
+    if (p.prec == PREC_F16X2) {
+        if (epi != EPI_SPADE) return hipErrorInvalidValue;     // the 2-term form exists for the gamma|beta convs only
+        conv_igemm_bf16x3_pp<EPI_SPADE, true><<<grid, 512, PP_LDS, s>>>(p, g);
+        return hipGetLastError();
+    }
     switch (epi) {
-        case EPI_BIAS: conv_igemm_bf16x3_pp<EPI_BIAS><<<grid, 512, PP_LDS, s>>>(p, g); break;
-        case EPI_RES: conv_igemm_bf16x3_pp<EPI_RES><<<grid, 512, PP_LDS, s>>>(p, g); break;
-        case EPI_SPADE: conv_igemm_bf16x3_pp<EPI_SPADE><<<grid, 512, PP_LDS, s>>>(p, g); break;
+        case EPI_BIAS: conv_igemm_bf16x3_pp<EPI_BIAS, false><<<grid, 512, PP_LDS, s>>>(p, g); break;
+        case EPI_RES: conv_igemm_bf16x3_pp<EPI_RES, false><<<grid, 512, PP_LDS, s>>>(p, g); break;
+        case EPI_SPADE: conv_igemm_bf16x3_pp<EPI_SPADE, false><<<grid, 512, PP_LDS, s>>>(p, g); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
 hipError_t launch_conv_igemm(const ConvParams& p, int epilogue, int tile, hipStream_t s) {
+    if (p.prec == PREC_F16X2) return tile == TILE_256x128_PP ? launch_pp(p, epilogue, s) : hipErrorInvalidValue;
     if (p.prec == PREC_BF16X3) {
         if (tile == TILE_256x128_PP) return launch_pp(p, epilogue, s);
         if (tile == TILE_128x128_HALO) return launch_halo(p, epilogue, 0, s);

@@ -58,7 +58,11 @@ struct ConvParams {
 // That is exactly the LDS row image the kernel wants (8 consecutive k of one half per ds_read_b128), so staging
 // is a plain 16-byte copy.  The conv computes a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 with
 // fp32 accumulation: per-product error <= ~3*2^-18 instead of fp32's 2^-24, at 16/3 of the fp32-MFMA rate.
-enum ConvPrecision : int { PREC_F32 = 0, PREC_BF16X3 = 1 };
+// PREC_F16X2 ("2-term" products, opt-in for the SPADE gamma|beta convs only): the activation is split in two fp16
+// halves (hi = f16_rn(v), lo = f16_rn(v - hi), ~22 bits) and the weight is ONE fp16 (11 bits, the lo half of its
+// chunk image is stored but not read): a * w ~= a_hi*w_hi + a_lo*w_hi on v_mfma_f32_16x16x32_f16, two MFMAs instead
+// of three, per-product error <= 2^-12 (the weight's rounding).  Same tensor layout as split-bf16, fp16 encodings.
+enum ConvPrecision : int { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_F16X2 = 2 };
 
 __host__ __device__ inline unsigned msr_bf16_rn(float v) {   // round-to-nearest-even, finite inputs
     union { float f; unsigned u; } c;
@@ -101,6 +105,21 @@ __device__ inline void msr_store_split4_dev(float* pixel, int c, float v0, float
     *reinterpret_cast<uint2*>(chunk + 16) = make_uint2(l01, l23);
 }
 
+// fp16 twins of the split helpers (PREC_F16X2 tensors): v_cvt_f16_f32 rounds to nearest even
+__host__ __device__ inline void msr_split_f16(float v, unsigned& hi, unsigned& lo) {
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    hi = (unsigned)__builtin_bit_cast(unsigned short, h);
+    lo = (unsigned)__builtin_bit_cast(unsigned short, l);
+}
+__host__ __device__ inline void msr_store_split4_f16(float* pixel, int c, float v0, float v1, float v2, float v3) {
+    unsigned h0, l0, h1, l1, h2, l2, h3, l3;
+    msr_split_f16(v0, h0, l0); msr_split_f16(v1, h1, l1); msr_split_f16(v2, h2, l2); msr_split_f16(v3, h3, l3);
+    unsigned* chunk = reinterpret_cast<unsigned*>(pixel) + (c & ~31) + ((c & 31) >> 1);
+    chunk[0] = h0 | (h1 << 16); chunk[1] = h2 | (h3 << 16);
+    chunk[16] = l0 | (l1 << 16); chunk[17] = l2 | (l3 << 16);
+}
+
 enum ConvTile : int { TILE_128x128 = 0, TILE_64x64 = 1, TILE_128x128_K16 = 2, TILE_128x128_HALO = 3, TILE_128x128_HALO16 = 4, TILE_256x128_PP = 5 };
 
 hipError_t conv_igemm_init();   // sets dynamic-LDS attributes once
@@ -131,7 +150,7 @@ struct SmallCinParams {
     int out_px, out_py, out_pb, out_off;
     int act;            // 0 none, 1 relu, 2 leaky(slope)
     float slope;
-    int out_split;      // write split-bf16 words for a PREC_BF16X3 consumer
+    int out_split;      // 1: write split-bf16 words for a PREC_BF16X3 consumer; 2: split-fp16 words (PREC_F16X2)
 };
 hipError_t launch_conv_smallcin(const SmallCinParams& p, hipStream_t s);
 hipError_t launch_split_bf16(const float* in, float* out, long n, hipStream_t s);

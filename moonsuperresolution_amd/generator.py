@@ -35,8 +35,10 @@ class Generator:
         device: HIP device ordinal (one process per GPU).
         precision: conv arithmetic — "bf16x3" (default: 3-term split-bf16 products on the bf16 MFMA with fp32
             accumulation; ~2e-5 relative L-inf end to end against the float64 oracle, 2.5x the fp32 throughput)
-            or "fp32" (exact fp32 MFMA, ~4e-6).  Both are far inside the 1e-3 parity bar.  Inputs, outputs,
-            weights and every non-conv op (moments, normalisation, epilogues, dense, head) are fp32 either way.
+            or "fp32" (exact fp32 MFMA, ~4e-6).  Both are far inside the 1e-3 parity bar.  "bf16x3_gbf16" is the
+            opt-in faster mode: bf16x3, with 2-term fp16 products (weight rounded to one fp16) in the SPADE
+            gamma|beta convs — 2-5e-4 end to end, inside the bar with a small margin.  Inputs, outputs, weights and
+            every non-conv op (moments, normalisation, epilogues, dense, head) are fp32 in every mode.
     """
 
     def __init__(self, image_size: int, batch_size: int, latent_dim: int = 256, variant: str = "gaugan",

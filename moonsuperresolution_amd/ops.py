@@ -9,7 +9,7 @@ import torch
 from . import _lib
 
 EPI_BIAS, EPI_RES, EPI_SPADE = 0, 1, 2
-TILE_128, TILE_64, TILE_128_K16, TILE_HALO, TILE_HALO16, TILE_PP, TILE_FRAG = 0, 1, 2, 3, 4, 5, 0x40
+TILE_128, TILE_64, TILE_128_K16, TILE_HALO, TILE_HALO16, TILE_PP, TILE_FRAG, TILE_F16X2 = 0, 1, 2, 3, 4, 5, 0x40, 0x80
 
 
 class OpContext:
@@ -74,6 +74,16 @@ def split_bf16(ctx: OpContext, x: torch.Tensor) -> torch.Tensor:
                                    torch.cuda.current_stream(x.device).cuda_stream)
     _lib.raise_for(ctx.lib, ctx.h, rc, "msr_op_split_bf16")
     return out
+
+
+def split_f16(x: torch.Tensor) -> torch.Tensor:
+    """fp32 -> split-fp16 words: every aligned group of 32 values becomes [32 x hi f16 | 32 x lo f16] with
+    hi = f16_rn(v), lo = f16_rn(v - hi) (the operand format of the 2-term gamma|beta mode); float32 storage."""
+    x = x.contiguous()
+    hi = x.to(torch.float16)
+    lo = (x - hi.float()).to(torch.float16)
+    hl = torch.stack([hi.reshape(-1, 32), lo.reshape(-1, 32)], 1).contiguous()     # [chunks][2][32]
+    return hl.view(torch.int16).reshape(-1).view(torch.float32).reshape(x.shape)
 
 
 def weights_bf16x3(w_kl: torch.Tensor) -> torch.Tensor:

@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--gather", action="store_true", help="all_gather the finished rows on every rank")
     ap.add_argument("--simulate-rank", type=int, default=-1, help="single process: take this rank's shard ...")
     ap.add_argument("--simulate-world", type=int, default=0, help="... of this many ranks (no process group)")
+    ap.add_argument("--no-reference", dest="reference", action="store_false",
+                    help="skip the generator-only pass (same calls, same streams, no tiler / stitcher) after the map")
     ap.add_argument("--precision", default="bf16x3")
     ap.add_argument("--pipeline", type=int, default=2)
     args = ap.parse_args()
@@ -142,6 +144,22 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     good_fraction = float(prod[2][:, :args.cols].float().mean()) if prod[2].numel() else 0.0
+    # generator-only reference: the same number of calls over the same handles / streams, no tiler and no stitcher
+    gen_only = None
+    if args.reference and calls and dsr._gens:
+        xb = torch.zeros((B, S, S, 2), device="cuda").uniform_(-0.5, 0.5)
+        ob = [torch.empty((B, S, S, 1), device="cuda") for _ in dsr._gens]
+        torch.cuda.synchronize()
+        tr = time.perf_counter()
+        cur = torch.cuda.current_stream()
+        for ps in dsr._pstreams:
+            ps.wait_stream(cur)
+        for c in range(calls):
+            k = c % len(dsr._gens)
+            with torch.cuda.stream(dsr._pstreams[k]):
+                dsr._gens[k].forward_device(xb, out=ob[k])
+        torch.cuda.synchronize()
+        gen_only = calls * B * (S / 512.0) ** 2 / (time.perf_counter() - tr)
     tot = torch.tensor([patches, calls, elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
         mx = tot.clone()
@@ -157,6 +175,8 @@ def main():
             "seconds_tiles_rank0": t_tiles, "seconds_gather_rank0": t_gather,
             "patches_per_s": patches / elapsed,
             "tiles512_per_s": calls * B * (S / 512.0) ** 2 / elapsed,
+            "generator_only_tiles512_per_s_rank0": gen_only,
+            "end_to_end_over_generator_only": (calls * B * (S / 512.0) ** 2 / t_tiles / gen_only) if gen_only else None,
             "good_fraction_of_rank0_rows": good_fraction, "gathered": bool(args.gather and world > 1),
             "canvas": list(dsr.dem_padded_shape), "shard": [shard_rank, shard_world], "tiles_this_rank": len(mine),
             "tiles_processed_this_rank": len(todo),

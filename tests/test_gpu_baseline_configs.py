@@ -8,8 +8,10 @@ setting GauGAN(512, 12) of run_GAN.sh:24-26 — against the CPU restatement of G
 (spade/models/model.py:564-567, spade.py:16-25; oracle/generator_ref.py), float64 at S = 256 and float32 at S = 512
 (its own rounding, ~4e-6, is far below the bar).
 
-Tolerance (BASELINE.json north_star): relative L-infinity max|y - ref| / max|ref| <= 1e-3 for the parity modes
-"fp32" and "bf16x3"; the measured values are printed and appended to gpurun_out/parity_baseline_configs.jsonl.
+Tolerance (BASELINE.json north_star): relative L-infinity max|y - ref| / max|ref| <= 1e-3 in every mode.  "fp32" and
+"bf16x3" sit 50-300x inside it (2e-5 / 4e-6); the opt-in "bf16x3_gbf16" (2-term fp16 products in the gamma|beta convs:
+the weight is rounded to one fp16, 2^-12 per product) is bounded by the same bar with a smaller margin (measured
+2-5e-4).  The measured values are printed and appended to gpurun_out/parity_baseline_configs.jsonl.
 """
 import json
 import os
@@ -68,7 +70,7 @@ def _record(**kw):
     print("parity", kw)
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32", "bf16x3_gbf16"])
 @pytest.mark.parametrize("S,B", [(256, 16), (512, 8), (512, 12)])
 def test_baseline_config_matches_oracle(hip_lib, S, B, precision):
     from moonsuperresolution_amd import Generator

@@ -169,3 +169,41 @@ def test_conv_spade_epilogue_bf16x3_split_output(ctx, tile, B, r, C, shift):
     v = torch.where(v >= 0, v, 0.2 * v)
     assert rel_linf(val.cpu()[:, 1:-1, 1:-1].numpy(), v.numpy()) <= 5e-5
     assert float(val.cpu()[:, 0].abs().max()) == 0 and float(val.cpu()[:, :, -1].abs().max()) == 0
+
+
+@pytest.mark.parametrize("B,r,C,shift", [(2, 16, 64, 0), (3, 128, 128, 0), (16, 64, 128, 1)])
+def test_conv_spade_epilogue_f16x2(ctx, B, r, C, shift):
+    """The opt-in 2-term form of the gamma|beta conv (MSR_FLAG_GB_F16X2; persistent ping-pong tile only): activation
+    = two fp16 halves, weight = ONE fp16, products on v_mfma_f32_16x16x32_f16 with fp32 accumulation.  The weight's
+    rounding (2^-12 relative per product, random sign over K = 1152 terms) bounds the result: rel L-inf <= 5e-4
+    against the float64 reference (observed ~1e-4); against a reference computed with the fp16-rounded weights the
+    kernel must agree like the 3-term one does (<= 5e-5): the activation split loses nothing."""
+    from moonsuperresolution_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(29 + B + r)
+    h = torch.relu(torch.randn((B, r, r, 128), generator=g)).cuda()
+    wg = (torch.randn((3, 3, 128, C), generator=g) / 34).cuda()
+    wb = (torch.randn((3, 3, 128, C), generator=g) / 34).cuda()
+    bg, bb = torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+    x = (3 + 2 * torch.randn((B, r >> shift, r >> shift, C), generator=g)).cuda()
+    mean = x.mean((0, 1, 2)).contiguous()
+    std = torch.sqrt(x.var((0, 1, 2), unbiased=False) + 1e-5).contiguous()
+    w, bias = ops.spade_layout(wg, wb, bg, bb)
+    y = ops.conv3x3(ctx, ops.split_f16(ops.pad_nhwc(h)), ops.split_f16(w), bias, r, epilogue=ops.EPI_SPADE, aux=x,
+                    aux_shift=shift, mean=mean, std=std, out_padded=True, tile=ops.TILE_PP | ops.TILE_F16X2,
+                    precision="bf16x3", out_split=True)
+    hi, lo = unsplit(y)
+    val = (hi + lo).cpu()[:, 1:-1, 1:-1].numpy()
+    xr = x.double().cpu()
+    if shift:
+        xr = xr.repeat_interleave(2, 1).repeat_interleave(2, 2)
+    xn = (xr - mean.double().cpu()) / std.double().cpu()
+
+    def ref(wg_, wb_):
+        v = ref_conv(h, wg_, bg, 1) * xn + ref_conv(h, wb_, bb, 1)
+        return torch.where(v >= 0, v, 0.2 * v).numpy()
+
+    e_full = rel_linf(val, ref(wg, wb))
+    e_rounded = rel_linf(val, ref(wg.half().float(), wb.half().float()))
+    print("f16x2 kernel: rel Linf vs fp64", e_full, " vs fp64 with fp16-rounded weights", e_rounded)
+    assert e_full <= 5e-4, e_full
+    assert e_rounded <= 5e-5, e_rounded
