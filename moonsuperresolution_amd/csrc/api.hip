@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -282,7 +283,7 @@ int upload_conv_weight(msr_handle* h, const std::string& key, const float* host,
     return upload(h, key, t.data(), floats);
 }
 
-struct ConvVariant { int tile; int wt_frag; };
+struct ConvVariant { int tile; int wt_frag; int ksplit; };   // ksplit 0: conv_pick_ksplit decides (small tiles)
 ConvVariant pick_conv_variant(int B, int rout, int N, int stride, int epi, int prec, int cin);
 
 // Output resolution of the conv a weight belongs to ("enc.ds3.kernel" -> S>>3, "gen.rb4...." -> sw<<3).
@@ -302,7 +303,9 @@ bool weight_uses_frag(msr_handle* h, const std::string& name, int N, int epi, in
 // MSR_FLAG_GB_F16X2: the gamma|beta convs that run the persistent ping-pong kernel take 2-term fp16 products; the
 // planner (conv precision, format of the mask embedding that feeds them) and the weight upload both ask this.
 bool gb_uses_f16x2(msr_handle* h, int rout, int N, int cin) {
-    return h->gb_f16x2 && pick_conv_variant(h->B, rout, N, 1, EPI_SPADE, PREC_BF16X3, cin).tile == TILE_256x128_PP;
+    if (!h->gb_f16x2) return false;
+    const ConvVariant v = pick_conv_variant(h->B, rout, N, 1, EPI_SPADE, PREC_BF16X3, cin);
+    return v.tile == TILE_256x128_PP && v.ksplit == 1;      // the K-split launches run the 3-term form
 }
 
 }  // namespace
@@ -586,21 +589,44 @@ int alloc_padded(msr_handle* h, const std::string& key, int r, int C, Padded* ou
 
 // Kernel variant of one conv layer.  Under bf16x3 it also fixes the weight layout, so msr_load_weight and the
 // planner must agree: both call this.
+// K split of the persistent ping-pong kernel for layers with fewer 16 x 16 x 128 tiles than CUs: whole chunk pairs
+// per range, a power of two, as many ranges as it takes to give every CU a work item.  0 = the layer is not one for
+// that kernel (it needs stride 1, r >= 16, Cin % 64 == 0, an input below the 2 GiB buffer-descriptor range and, split
+// or not, at least `min_items` work items — below that the small-tile split-K kernels are faster).
+int pp_ksplit(int B, int rout, int N, int stride, int cin, long min_items = 128) {
+    static const bool off = std::getenv("MSR_PP_KSPLIT") && std::atoi(std::getenv("MSR_PP_KSPLIT")) == 0;
+    if (stride != 1 || rout < 16 || cin % 64 || N % 128) return 0;
+    if ((size_t)B * (rout + 2) * (rout + 2) * cin * sizeof(float) >= ((size_t)1 << 31)) return 0;
+    const long tiles = (long)B * (rout / 16) * (rout / 16) * (N / 128);
+    if (tiles >= 256) return 1;
+    if (off) return 0;
+    const int pairs = cin / 64;
+    int ks = 1;
+    while (tiles * ks * 2 <= 256 && pairs % (ks * 2) == 0) ks *= 2;
+    return tiles * ks >= min_items ? ks : 0;
+}
+
 ConvVariant pick_conv_variant(int B, int rout, int N, int stride, int epi, int prec, int cin) {
     ConvVariant v;
     const int M = B * rout * rout;
     v.tile = conv_pick_tile(M, N, epi, prec, 9 * (cin / 32));
     v.wt_frag = 0;
+    v.ksplit = 0;
     if (prec == PREC_BF16X3) {
         const long big_blocks = (long)((M + 127) / 128) * (N / 128);
-        if (v.tile == TILE_64x64 || big_blocks < 256) {
+        const int pks = pp_ksplit(B, rout, N, stride, cin);
+        if (pks >= 1) {
+            // LDS-staged input halo, 512-thread ping-pong form (one persistent workgroup per CU, 16 x 16 pixels x 128
+            // channels per tile): 10-25 % faster than two 256-thread workgroups per CU as soon as it fills the chip
+            // once; with fewer tiles than CUs, K ranges supply the work items (pks > 1).
+            v.tile = TILE_256x128_PP;
+            v.ksplit = pks;
+        } else if (v.tile == TILE_64x64 || big_blocks < 256) {
             v.wt_frag = 1;   // few workgroups (with split-K): B fragments straight to VGPRs, +18 % on the small tile
         } else if (stride == 1 && rout >= 16 && cin % 64 == 0 &&
                    (size_t)B * (rout + 2) * (rout + 2) * cin * sizeof(float) < ((size_t)1 << 31)) {   // raw buffer loads: 2 GiB
-            // LDS-staged input halo.  The 512-thread ping-pong form (one workgroup per CU, 16 x 16 pixels) is
-            // 10-25 % faster as soon as it fills the chip once; below that, two 256-thread workgroups per CU.
-            const long pp_blocks = (long)B * (rout / 16) * (rout / 16) * (N / 128);
-            v.tile = pp_blocks >= 256 ? TILE_256x128_PP : TILE_128x128_HALO16;
+            v.tile = TILE_128x128_HALO16;     // only reached with MSR_PP_KSPLIT=0: two 256-thread workgroups per CU
+            v.ksplit = 1;
         }
     }
     return v;
@@ -621,7 +647,7 @@ Op conv_op(const Padded& in, const float* wt, const float* bias, int B, int rout
     const ConvVariant cv = pick_conv_variant(B, rout, N, stride, epi, prec, in.C);
     op.tile = cv.tile;
     c.wt_frag = cv.wt_frag;
-    c.ksplit = (op.tile == TILE_128x128_HALO || op.tile == TILE_128x128_HALO16 || op.tile == TILE_256x128_PP) ? 1 : conv_pick_ksplit(B * rout * rout, N, 9 * (in.C / 32), op.tile, prec);
+    c.ksplit = cv.ksplit > 0 ? cv.ksplit : conv_pick_ksplit(B * rout * rout, N, 9 * (in.C / 32), op.tile, prec);
     c.partial = nullptr;   // bound to the handle's workspace at launch
     op.flops = 2.0 * B * rout * rout * (double)in.C * N * 9;
     return op;

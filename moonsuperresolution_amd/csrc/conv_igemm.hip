@@ -266,10 +266,26 @@ __device__ __forceinline__ void halo16_epilogue_load(const ConvParams& p, float4
             cv[4 + jj] = *reinterpret_cast<const float4*>(p.mean + ch);
             cv[6 + jj] = *reinterpret_cast<const float4*>(p.stdv + ch);
         }
-    } else {
+    } else if constexpr (EPI != EPI_PARTIAL) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) cv[j] = *reinterpret_cast<const float4*>(p.bias + n0 + wn * 64 + j * 16 + 4 * cg);
     }
+}
+
+// K-split ping-pong launches (few tiles: a workgroup owns one K range of a tile): the raw accumulators of range `ks`
+// go to partial[ks][B, Hout, Wout, N] with 16-byte stores; splitk_epilogue_kernel sums the ranges in a fixed order and
+// applies the layer's epilogue.
+__device__ __forceinline__ void halo16_epilogue_partial(const ConvParams& p, f32x4 (&acc)[4][4], int wm, int wn, int lane,
+                                                        int n0, int tx0, int ty0, int b0, int ks) {
+    const int px = lane & 15, cg = lane >> 4;
+    const int x = tx0 + px, y0 = ty0 + wm * 4;
+    float* const pbase = p.partial + (size_t)ks * ((size_t)p.B * p.Hout * p.Wout * p.N) +
+                         ((size_t)b0 * p.Hout * p.Wout + x) * p.N + n0 + wn * 64 + 4 * cg;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<float4*>(pbase + (size_t)(y0 + i) * p.Wout * p.N + j * 16) = f4(acc[i][j]);
 }
 
 template <int EPI, bool SPLIT>
@@ -1086,29 +1102,37 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
     // dealt round-robin over the 8 XCDs, so XCD x owns a contiguous range of logical tiles (as xcd_remap) and its
     // gridDim.x / 8 workgroups take consecutive tiles of that range in every round: the tiles in flight on an XCD
     // share their halo (same pixels, next channel block) and weights in that XCD's L2.
+    // With p.ksplit > 1 (fewer tiles than CUs) a work item is (K range, tile): range ks covers chunk pairs
+    // [ks * ppi, (ks + 1) * ppi), items are numbered range-major so that neighbours still share their halo.
+    const int ksn = p.ksplit > 1 ? p.ksplit : 1;
+    const int ppi = (p.Cin / (2 * BKC)) / ksn;                                 // chunk pairs per item
+    const unsigned kbytes = (unsigned)ppi * 2u * BKC * 4u;                      // byte offset of one range (input and weights)
+    const int items = g.tiles_mn * ksn;
     const int slots = gridDim.x >> 3, xcd = blockIdx.x & 7;
-    const int tq = g.tiles_mn >> 3, tr = g.tiles_mn & 7;
+    const int tq = items >> 3, tr = items & 7;
     const int cnt = tq + (xcd < tr ? 1 : 0);
     const int base = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
     int tile = blockIdx.x >> 3;                   // index inside the XCD's range
     if (tile >= cnt) return;
 
     // per-tile state is scalar: tile origin (pixels, channel block) and its byte offsets in the input / weights
-    int n0, tx0, ty0, b0;
+    int n0, tx0, ty0, b0, ks0;
     unsigned h_tile, w_tile;
-#define MSR_DECODE(T_, N0_, TX_, TY_, B_, HT_, WT_)                                               \
+#define MSR_DECODE(T_, N0_, TX_, TY_, B_, HT_, WT_, KS_)                                          \
     {                                                                                            \
-        const int tn_ = (T_) % g.tiles_n;                                                        \
-        int tmi_ = (T_) / g.tiles_n;                                                             \
+        KS_ = (T_) / g.tiles_mn;                                                                 \
+        const int t_ = (T_) - KS_ * g.tiles_mn;                                                  \
+        const int tn_ = t_ % g.tiles_n;                                                          \
+        int tmi_ = t_ / g.tiles_n;                                                               \
         TX_ = (tmi_ % g.tiles_x) << 4;                                                           \
         tmi_ /= g.tiles_x;                                                                       \
         TY_ = (tmi_ % g.tiles_y) << 4;                                                           \
         B_ = tmi_ / g.tiles_y;                                                                   \
         N0_ = tn_ * BN;                                                                          \
-        HT_ = (unsigned)((B_) * p.in_pb + (TY_) * p.in_py + (TX_) * p.Cin) * 4u;                  \
-        WT_ = (unsigned)((N0_) * p.Cin) * 4u;                                                    \
+        HT_ = (unsigned)((B_) * p.in_pb + (TY_) * p.in_py + (TX_) * p.Cin) * 4u + (unsigned)KS_ * kbytes; \
+        WT_ = (unsigned)((N0_) * p.Cin) * 4u + (unsigned)KS_ * kbytes;                           \
     }
-    MSR_DECODE(base + tile, n0, tx0, ty0, b0, h_tile, w_tile)
+    MSR_DECODE(base + tile, n0, tx0, ty0, b0, h_tile, w_tile, ks0)
 
     int h_goff[H_ITEMS], h_loff[H_ITEMS];         // tile-relative byte offsets / LDS float offsets
 #pragma unroll
@@ -1136,7 +1160,6 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
     }
     f32x4 acc[4][4];
 
-    const int chunks = p.Cin / BKC;               // even: the unrolled body is a PAIR of chunks
     const unsigned w_tap_bytes = (unsigned)((size_t)p.N * p.Cin * sizeof(float));
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.in), 0, (int)((size_t)p.B * p.in_pb * sizeof(float)), 0x00020000);
@@ -1242,7 +1265,7 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
     {                                                                                            \
         MSR_STAMP()                                                                              \
         MSR_R(T, LASTP)                                                                          \
-        if ((LASTP) && (T) == 16) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0); \
+        if ((LASTP) && (T) == 16 && EPI != EPI_PARTIAL) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0); \
         MSR_STAMP()                                                                              \
         __syncthreads();                                                                         \
         MSR_STAMP()                                                                              \
@@ -1279,8 +1302,8 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
     for (;;) {
         const int tnext = tile + slots;
         const bool has_next = tnext < cnt;
-        int n0n, tx0n, ty0n, b0n;
-        MSR_DECODE(base + (has_next ? tnext : tile), n0n, tx0n, ty0n, b0n, h_next, w_next)
+        int n0n, tx0n, ty0n, b0n, ks0n;
+        MSR_DECODE(base + (has_next ? tnext : tile), n0n, tx0n, ty0n, b0n, h_next, w_next, ks0n)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1289,7 +1312,7 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
         h_pair = 0;
         w_pair = 0;
-        for (int pr = 0; pr < chunks / 2 - 1; ++pr) {
+        for (int pr = 0; pr < ppi - 1; ++pr) {
 #ifdef MSR_PP_STAMPS
             dbg_on = blockIdx.x == 8 && pr == 2 && dbg_n == 0;
 #endif
@@ -1303,10 +1326,11 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
         MSR_PAIR(true)
         // The epilogue of a tile shares a barrier interval with R(0) of the next one: X runs it beside Y's last M,
         // Y beside X's first M of the next tile.  Its stores are not waited for.
-        halo16_epilogue<EPI>(p, ge, acc, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0, xpre, cpre);
+        if constexpr (EPI == EPI_PARTIAL) halo16_epilogue_partial(p, acc, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0, ks0);
+        else halo16_epilogue<EPI>(p, ge, acc, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0, xpre, cpre);
         if (!has_next) break;
         tile = tnext;
-        n0 = n0n; tx0 = tx0n; ty0 = ty0n; b0 = b0n;
+        n0 = n0n; tx0 = tx0n; ty0 = ty0n; b0 = b0n; ks0 = ks0n;
         h_tile = h_next;
         w_tile = w_next;
     }
@@ -1466,6 +1490,7 @@ static hipError_t set_attr_halo() {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_LDS)) != hipSuccess)      \
         return e;
     MSR_SETPP(EPI_BIAS, false) MSR_SETPP(EPI_RES, false) MSR_SETPP(EPI_SPADE, false) MSR_SETPP(EPI_SPADE, true)
+    MSR_SETPP(EPI_PARTIAL, false)
 #undef MSR_SETPP
 #define MSR_SET(EPI)                                                                                          \
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_halo<EPI, 0>),               \
@@ -1707,9 +1732,10 @@ static hipError_t launch_halo(const ConvParams& p, int epi, int sh, hipStream_t 
 static hipError_t launch_pp(const ConvParams& p, int epi, hipStream_t s) {
     TileGeom g;
     if (!make_geom(p, 256, 128, 32, g)) return hipErrorInvalidValue;
-    if (g.tb != 1 || g.th_l != 4 || g.tw_l != 4 || p.stride != 1 || p.KH != 3 || p.KW != 3 || p.ksplit > 1 ||
-        p.Cin % 64)
+    if (g.tb != 1 || g.th_l != 4 || g.tw_l != 4 || p.stride != 1 || p.KH != 3 || p.KW != 3 || p.Cin % 64)
         return hipErrorInvalidValue;
+    const int ksn = p.ksplit > 1 ? p.ksplit : 1;
+    if ((p.Cin / 64) % ksn) return hipErrorInvalidValue;          // every K range is a whole number of chunk pairs
     if ((size_t)p.B * p.in_pb * sizeof(float) >= ((size_t)1 << 31)) return hipErrorInvalidValue;   // buffer descriptor range
     // persistent: one workgroup per CU (144 KB of LDS each), a multiple of 8 so that every XCD gets the same count
     static int n_cu = 0;
@@ -1720,7 +1746,21 @@ static hipError_t launch_pp(const ConvParams& p, int epi, hipStream_t s) {
         n_cu = prop.multiProcessorCount & ~7;
         if (n_cu < 8) n_cu = 8;
     }
-    const int grid = g.tiles_mn < n_cu ? ((g.tiles_mn + 7) & ~7) : n_cu;
+    const int items = g.tiles_mn * ksn;
+    const int grid = items < n_cu ? ((items + 7) & ~7) : n_cu;
+    if (ksn > 1) {
+        // few tiles: K ranges fill the chip, raw accumulators go to the split-K workspace, one more pass finishes
+        if (!p.partial || p.prec != PREC_BF16X3) return hipErrorInvalidValue;
+        conv_igemm_bf16x3_pp<EPI_PARTIAL, false><<<grid, 512, PP_LDS, s>>>(p, g);
+        const int Cout = epi == EPI_SPADE ? p.N / 2 : p.N;
+        long eb = ((long)p.B * p.Hout * p.Wout * (Cout / 4) + 255) / 256;
+        if (eb > 4096) eb = 4096;
+        if (epi == EPI_BIAS) splitk_epilogue_kernel<EPI_BIAS><<<(int)eb, 256, 0, s>>>(p);
+        else if (epi == EPI_RES) splitk_epilogue_kernel<EPI_RES><<<(int)eb, 256, 0, s>>>(p);
+        else if (epi == EPI_SPADE) splitk_epilogue_kernel<EPI_SPADE><<<(int)eb, 256, 0, s>>>(p);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     if (p.prec == PREC_F16X2) {
         if (epi != EPI_SPADE) return hipErrorInvalidValue;     // the 2-term form exists for the gamma|beta convs only
         conv_igemm_bf16x3_pp<EPI_SPADE, true><<<grid, 512, PP_LDS, s>>>(p, g);

@@ -94,6 +94,8 @@ class DEMSuperResolution:
         self._gens = None
         self._pstreams = None
         self._prep_stream = None
+        self._bufs = None
+        self._batches = None
         self._last = (None, 0, 0)
         self._last_calls = None
         S, s = self.image_size, self.stride
@@ -308,23 +310,29 @@ class DEMSuperResolution:
         self._last_calls = None
         with torch.cuda.device(dev):
             cur = torch.cuda.current_stream(dev)
-            cur.wait_event(st["event"])
             for t in (sx, sy, mm_sel, st["keys"], st["dmm"]):
                 t.record_stream(cur)
-            preds = torch.empty((max(total, 1), S, S), dtype=torch.float32, device=dev)
             if self._gen is not None:
                 # The calls of a tile are independent batches: alternate them over `pipeline` generator handles, each
                 # on its own stream, so that the low-occupancy head of one call overlaps the tail of the other.
-                # Patches go from the rasters to `preds` without leaving HBM.
+                # Patches go from the rasters to `preds` without leaving HBM.  `preds` is one of two persistent
+                # buffers (no allocation per tile — a fresh 0.5 GB hipMalloc drains the device), and the generator
+                # streams wait only for the events they need (this tile's preparation; the stitcher pass that last read
+                # this buffer, two tiles ago), so tile t+1 starts generating while tile t is being stitched.
                 if self._gens is None:
                     self._make_pipeline()
                 for g in self._gens[1:]:       # a load() on the base generator after construction: the clones follow
                     if g.weights_version != self._gen.weights_version:
                         g.load(self._gen._weights)
                         g.weights_version = self._gen.weights_version
-                batches = [torch.empty((B, S, S, 2), dtype=torch.float32, device=dev) for _ in self._gens]
+                buf = self._tile_buffers(st["cap"])
+                preds, batches = buf["preds"], self._batches
                 for ps in self._pstreams:
-                    ps.wait_stream(cur)
+                    ps.wait_event(st["event"])
+                    if buf["free"] is not None:
+                        ps.wait_event(buf["free"])
+                    for t in (sx, sy, mm_sel):
+                        t.record_stream(ps)
                 for c in range(ncall):
                     k = c % len(self._gens)
                     with torch.cuda.stream(self._pstreams[k]):
@@ -335,18 +343,33 @@ class DEMSuperResolution:
                         self._gens[k].forward_device(batches[k], out=preds[c * B:(c + 1) * B].unsqueeze(-1))
                 for ps in self._pstreams:
                     cur.wait_stream(ps)
-                    for t in batches + [preds, sx, sy, mm_sel]:
-                        t.record_stream(ps)
-            else:
-                batch = torch.empty((B, S, S, 2), dtype=torch.float32, device=dev)
-                for c in range(ncall):
-                    rc = lib.msr_extract_patches(h, self.img_padded.data_ptr(), self.dem_padded.data_ptr(), rows, cols,
-                                                 sx[c * B:].data_ptr(), sy[c * B:].data_ptr(), mm_sel[c * B:].data_ptr(),
-                                                 B, batch.data_ptr(), self._stream())
-                    _lib.raise_for(lib, h, rc, "msr_extract_patches")
-                    out = np.array(self.model(batch.cpu().numpy(), training=False))[:, :, :, -1]
-                    preds[c * B:(c + 1) * B] = torch.from_numpy(np.ascontiguousarray(out, dtype=np.float32)).to(dev)
+                cur.wait_event(st["event"])
+                out = self.rebuildTile(preds, st["keys"], st["dmm"], nv)
+                buf["free"] = torch.cuda.Event()
+                buf["free"].record(cur)
+                return out
+            cur.wait_event(st["event"])
+            preds = torch.empty((max(total, 1), S, S), dtype=torch.float32, device=dev)
+            batch = torch.empty((B, S, S, 2), dtype=torch.float32, device=dev)
+            for c in range(ncall):
+                rc = lib.msr_extract_patches(h, self.img_padded.data_ptr(), self.dem_padded.data_ptr(), rows, cols,
+                                             sx[c * B:].data_ptr(), sy[c * B:].data_ptr(), mm_sel[c * B:].data_ptr(),
+                                             B, batch.data_ptr(), self._stream())
+                _lib.raise_for(lib, h, rc, "msr_extract_patches")
+                out = np.array(self.model(batch.cpu().numpy(), training=False))[:, :, :, -1]
+                preds[c * B:(c + 1) * B] = torch.from_numpy(np.ascontiguousarray(out, dtype=np.float32)).to(dev)
             return self.rebuildTile(preds, st["keys"], st["dmm"], nv)
+
+    def _tile_buffers(self, cap: int):
+        """Two persistent prediction buffers [cap, S, S] used by alternate tiles, and one input batch per handle."""
+        S, B = self.image_size, self.batch_size
+        if self._bufs is None or self._bufs[0]["preds"].shape[0] < cap:
+            self._bufs = [{"preds": torch.empty((cap, S, S), dtype=torch.float32, device=self.device), "free": None}
+                          for _ in range(2)]
+            self._batches = [torch.empty((B, S, S, 2), dtype=torch.float32, device=self.device) for _ in self._gens]
+            self._buf_turn = 0
+        self._buf_turn ^= 1
+        return self._bufs[self._buf_turn]
 
     def processTile(self, px: int, py: int):
         """process_full_tiles.py:431-479 without the disk write: returns (mean, std, good) device tensors [T,T].

@@ -42,6 +42,21 @@ def test_conv_bias(ctx, B, r, cin, cout, stride, tile):
     assert rel_linf(y.cpu().numpy(), ref_conv(x, w, b, stride).numpy()) <= 1e-5
 
 
+def test_conv_residual_bf16x3_pingpong_ksplit(ctx):
+    """Residual epilogue through the K-split ping-pong launch (rb2 conv_2 at S = 512, B = 8: 64 tiles x 4 K ranges)."""
+    from moonsuperresolution_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    B, r, cin, cout = 2, 16, 256, 128
+    x = torch.randn((B, r, r, cin), generator=g).cuda()
+    w = (torch.randn((3, 3, cin, cout), generator=g) / 48).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    res = torch.randn((B, r >> 1, r >> 1, cout), generator=g).cuda()
+    y = ops.conv3x3(ctx, ops.split_bf16(ctx, ops.pad_nhwc(x)), ops.split_bf16(ctx, ops.kernel_layout(w)), b, r,
+                    epilogue=ops.EPI_RES, aux=res, aux_shift=1, tile=5 + 256 * 4, precision="bf16x3")
+    up = res.double().cpu().repeat_interleave(2, 1).repeat_interleave(2, 2)
+    assert rel_linf(y.cpu().numpy(), (ref_conv(x, w, b, 1) + up).numpy()) <= 5e-5
+
+
 @pytest.mark.parametrize("shift,tile", [(0, 0), (1, 0), (1, 1), (1, 1 + 256 * 2)])
 def test_conv_residual_with_upsample_fold(ctx, shift, tile):
     from moonsuperresolution_amd import ops
@@ -99,7 +114,9 @@ def test_untileable_shape_is_rejected(ctx):
     (2, 8, 128, 128, 1, 1 + 256 * 4), (16, 1, 64, 64, 1, 1), (2, 16, 64, 128, 1, 3), (1, 32, 128, 256, 1, 3),
     (2, 16, 64, 128, 1, 4), (1, 32, 128, 256, 1, 4), (3, 16, 128, 256, 1, 4),
     (2, 16, 64, 128, 1, 5), (1, 32, 128, 256, 1, 5), (3, 16, 128, 256, 1, 5),
-    (3, 128, 64, 256, 1, 5), (16, 64, 64, 256, 1, 5)])   # 384 / 512 tiles on 256 persistent workgroups: 1-2 tiles each
+    (3, 128, 64, 256, 1, 5), (16, 64, 64, 256, 1, 5),    # 384 / 512 tiles on 256 persistent workgroups: 1-2 tiles each
+    (2, 16, 128, 256, 1, 5 + 256 * 2), (1, 32, 256, 128, 1, 5 + 256 * 4), (3, 16, 1024, 128, 1, 5 + 256 * 16),
+    (8, 16, 512, 1024, 1, 5 + 256 * 4)])                 # K-split ping-pong: (K range, tile) work items + split-K pass
 def test_conv_bf16x3(ctx, B, r, cin, cout, stride, tile, frag):
     """3-term split-bf16 products, fp32 accumulation: error bound ~3*2^-18 per product -> rel L-inf <= 5e-5.
     Three kernels: LDS-staged weights (tiles 0/1), weights in VGPRs (| 0x40), LDS-staged input halo (tile 3 on the
@@ -142,6 +159,7 @@ def test_split_bf16_words(ctx):
     (0, 2, 16, 64, 0), (3, 2, 16, 64, 0), (4, 2, 16, 64, 0), (5, 2, 16, 64, 0),
     (5, 3, 128, 128, 0),      # 384 ping-pong tiles on 256 persistent workgroups: 1-2 tiles each (the bench regime)
     (5, 16, 64, 128, 1),      # 512 tiles, x read through the folded 2x up-sample (rb5 spade_1 at S=256, B=16)
+    (5 + 256 * 2, 4, 16, 256, 1),     # K-split ping-pong (2 ranges of one chunk pair each) + split-K SPADE pass
     (4, 3, 32, 256, 1)])      # 192 tiles of the 2-workgroups-per-CU halo form
 def test_conv_spade_epilogue_bf16x3_split_output(ctx, tile, B, r, C, shift):
     """The SPADE epilogue of the bf16x3 kernels writing split-bf16 words into a zero-bordered tensor, including the
