@@ -99,6 +99,12 @@ const char* msr_weight_name(const msr_handle* h, int32_t i, int64_t* shape4, int
  * batch must equal cfg.batch_size (the reference's sampler enforces the same). */
 int msr_forward(msr_handle* h, const float* in_dev, const float* eps_dev, float* out_dev, int32_t batch,
                 void* stream);
+/* on != 0: msr_forward captures its launch plan (~100 kernels on the call's stream and the handle's auxiliary stream)
+ * into a HIP graph the first time it sees an (in_dev, eps_dev, out_dev) pointer triple and replays it with ONE
+ * hipGraphLaunch afterwards (up to 8 triples are kept; further ones, the NULL stream and profiled calls launch
+ * eagerly).  For callers that reuse their buffers — the B = 1 latency case of the serial call at
+ * process_full_tiles.py:338.  Results are identical (same kernels, same order).  on == 0 drops the graphs. */
+int msr_graph_enable(msr_handle* h, int32_t on);
 /* Latent z [batch, latent] of the last msr_forward (debug / parity aid), copied to a device buffer. */
 int msr_last_latent(msr_handle* h, float* z_dev, void* stream);
 
