@@ -99,6 +99,16 @@ const char* msr_weight_name(const msr_handle* h, int32_t i, int64_t* shape4, int
  * batch must equal cfg.batch_size (the reference's sampler enforces the same). */
 int msr_forward(msr_handle* h, const float* in_dev, const float* eps_dev, float* out_dev, int32_t batch,
                 void* stream);
+/* msr_forward for callers that pipeline independent calls over two handles on two streams (the tile loop of
+ * process_full_tiles.py:453-474 issues its batches one after the other; they do not depend on each other): the call's
+ * latency-bound first part (encoder, dense layers, the low-resolution blocks: ~20 % of a call at low occupancy) is
+ * launched at once, its matrix-bound part (from the first layer that fills the chip) waits for `gate_event`
+ * (a hipEvent_t the caller recorded at the end of the previous call, on the other stream).  The heavy parts of
+ * consecutive calls then run back to back and every call's head hides under its predecessor's tail — free-running
+ * streams settle into either a favourable or an unfavourable phase (+6 % / -4 % against one stream), this is the
+ * favourable one by construction.  gate_event == NULL: plain msr_forward.  Not captured into graphs. */
+int msr_forward_gated(msr_handle* h, const float* in_dev, const float* eps_dev, float* out_dev, int32_t batch,
+                      void* stream, void* gate_event);
 /* on != 0: msr_forward captures its launch plan (~100 kernels on the call's stream and the handle's auxiliary stream)
  * into a HIP graph the first time it sees an (in_dev, eps_dev, out_dev) pointer triple and replays it with ONE
  * hipGraphLaunch afterwards (up to 8 triples are kept; further ones, the NULL stream and profiled calls launch

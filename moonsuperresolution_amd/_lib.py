@@ -42,6 +42,7 @@ SYMBOLS = [
     ("msr_weight_count", C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("msr_weight_name", C.c_char_p, [_P, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     ("msr_forward", C.c_int, [_P, _P, _P, _P, C.c_int32, _P]),
+    ("msr_forward_gated", C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P]),
     ("msr_graph_enable", C.c_int, [_P, C.c_int32]),
     ("msr_last_latent", C.c_int, [_P, _P, _P]),
     ("msr_patch_stats", C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_float, _P, _P, _P]),

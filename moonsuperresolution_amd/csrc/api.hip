@@ -90,6 +90,7 @@ struct msr_handle {
     struct GraphEntry { const float* in; const float* eps; float* out; hipGraph_t graph; hipGraphExec_t exec; };
     int graph_on = 0;
     std::vector<GraphEntry> graphs;
+    int gate_op = -1;                            // index of the first op of the matrix-bound part (msr_forward_gated)
     // profiling
     int prof_on = 0;                               // 0 off, 1 every launch, 2 runs of conv launches only
     std::vector<ProfRec> prof;
@@ -1027,6 +1028,12 @@ int ensure_plan(msr_handle* h) {
     int rc = h->variant == MSR_PIX2PIX ? plan_pix2pix(h) : plan_spade(h);
     if (rc) return rc;
     h->fwd_flops = 0;
+    h->gate_op = -1;
+    for (size_t k = 0; k < h->ops.size(); ++k)
+        if (h->ops[k].type == OP_CONV && h->ops[k].tile == TILE_256x128_PP && h->ops[k].conv.ksplit == 1) {
+            h->gate_op = (int)k;     // first layer that fills the chip with persistent ping-pong tiles
+            break;
+        }
     size_t need = 0, stat_need = 0;
     for (auto& op : h->ops) {
         h->fwd_flops += op.flops;
@@ -1058,7 +1065,8 @@ hipEvent_t get_event(msr_handle* h) {
 }
 
 // The launch plan of one generator(call): every kernel of msr_forward, on `s` and the handle's auxiliary stream.
-int launch_all(msr_handle* h, const float* in_dev, const float* eps_dev, float* out_dev, hipStream_t s) {
+int launch_all(msr_handle* h, const float* in_dev, const float* eps_dev, float* out_dev, hipStream_t s,
+               hipEvent_t gate = nullptr) {
     // Fork: ops that need only the call's input go to the auxiliary stream.  With per-kernel profiling on they are
     // simply not timed (the brackets of the main-stream kernels stay valid: waits sit before the start event).
     const bool use_aux = h->aux != nullptr;
@@ -1089,8 +1097,16 @@ int launch_all(msr_handle* h, const float* in_dev, const float* eps_dev, float* 
         }
         run = ProfRec{FAM_CONV, nullptr, nullptr, 0.0, 0.0, 0};
     };
+    int op_index = -1;
     for (auto& op : h->ops) {
+        ++op_index;
         if (use_aux && op.on_aux) continue;
+        if (gate && op_index == h->gate_op) {
+            // msr_forward_gated: the matrix-bound part of this call starts only after the caller's event (the end of
+            // the previous call on another handle / stream); everything before it overlaps that call's tail
+            if (h->prof_on == 2) close_run();
+            HIPCHK(h, hipStreamWaitEvent(s, gate, 0));
+        }
         if (h->prof_on == 2 && (op.type != OP_CONV || (use_aux && op.wait))) close_run();
         if (use_aux && op.wait) HIPCHK(h, hipStreamWaitEvent(s, op.wait, 0));
         hipEvent_t ea = nullptr, eb = nullptr;
@@ -1203,6 +1219,20 @@ int msr_forward(msr_handle* h, const float* in_dev, const float* eps_dev, float*
     h->graphs.push_back(e);
     HIPCHK(h, hipGraphLaunch(e.exec, s));
     return MSR_OK;
+}
+
+int msr_forward_gated(msr_handle* h, const float* in_dev, const float* eps_dev, float* out_dev, int32_t batch,
+                      void* stream_v, void* gate_event) {
+    if (!h) return MSR_ERR_INVALID;
+    if (!gate_event) return msr_forward(h, in_dev, eps_dev, out_dev, batch, stream_v);
+    if (!in_dev || !out_dev) return fail(h, MSR_ERR_INVALID, "msr_forward_gated: null tensor pointer");
+    if (batch != h->B) return fail(h, MSR_ERR_INVALID, "batch %d != batch_size %d", batch, h->B);
+    if (h->variant == MSR_GAUGAN && !eps_dev)
+        return fail(h, MSR_ERR_INVALID, "variant gaugan needs the sampler noise eps [B, latent_dim]");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = ensure_plan(h);
+    if (rc) return rc;
+    return launch_all(h, in_dev, eps_dev, out_dev, (hipStream_t)stream_v, (hipEvent_t)gate_event);
 }
 
 int msr_graph_enable(msr_handle* h, int32_t on) {

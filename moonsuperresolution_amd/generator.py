@@ -104,10 +104,12 @@ class Generator:
 
     # -- the call ------------------------------------------------------------------------------------
     def forward_device(self, batch: torch.Tensor, eps: Optional[torch.Tensor] = None,
-                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       out: Optional[torch.Tensor] = None, gate: Optional[torch.cuda.Event] = None) -> torch.Tensor:
         """Device fast path: ``batch`` [B,S,S,2] float32 on this GPU -> [B,S,S,1] on the GPU (no host copy).
 
-        Asynchronous on torch's current stream."""
+        Asynchronous on torch's current stream.  ``gate``: an event recorded at the end of the previous, independent
+        call on another handle / stream — the matrix-bound part of this call waits for it, the latency-bound head
+        does not (msr_forward_gated)."""
         S, B = self.image_size, self.batch_size
         if tuple(batch.shape) != (B, S, S, 2):
             raise ValueError(f"expected a batch of shape {(B, S, S, 2)} (batch_size is fixed at construction, "
@@ -125,7 +127,11 @@ class Generator:
             eps = eps.to(device=self.device, dtype=torch.float32).contiguous()
             eps_ptr = eps.data_ptr()
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        rc = self._lib.msr_forward(self._h, batch.data_ptr(), eps_ptr, out.data_ptr(), B, stream)
+        if gate is not None:
+            rc = self._lib.msr_forward_gated(self._h, batch.data_ptr(), eps_ptr, out.data_ptr(), B, stream,
+                                             C.c_void_p(gate.cuda_event))
+        else:
+            rc = self._lib.msr_forward(self._h, batch.data_ptr(), eps_ptr, out.data_ptr(), B, stream)
         _lib.raise_for(self._lib, self._h, rc, "msr_forward")
         return out
 
