@@ -1022,6 +1022,11 @@ int ensure_plan(msr_handle* h) {
     if (!h->aux) {
         HIPCHK(h, hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        // First use now: HIP binds a stream to a hardware queue when it is first used, in order, and queues whose ids
+        // are equal modulo 4 share a dispatch pipe (profiles/r02_raster_queue_pairing.txt).  Callers that pipeline two
+        // handles plan them back to back (Generator.prepare) so that their four busy streams land on four pipes.
+        float* touch = nullptr;
+        if (dev_alloc(h, "ws.aux_touch", 4, false, &touch) == MSR_OK) HIPCHK(h, hipMemsetAsync(touch, 0, 16, h->aux));
     }
     if (h->mom_partial) { hipFree(h->mom_partial); h->mom_partial = nullptr; }
     if (h->dense_partial) { hipFree(h->dense_partial); h->dense_partial = nullptr; }

@@ -147,6 +147,10 @@ class Generator:
             y = self.forward_device(x.to(self.device, non_blocking=False))
             return y.cpu().numpy()
 
+    def prepare(self) -> None:
+        """Build the launch plan now (workspace, auxiliary stream) instead of at the first call."""
+        self.forward_flops()
+
     def use_graph(self, on: bool = True) -> None:
         """Replay the launch plan as a HIP graph for calls that repeat their (input, noise, output) buffers
         (msr_graph_enable): lower single-call latency; results identical."""

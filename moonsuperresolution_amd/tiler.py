@@ -94,6 +94,10 @@ class DEMSuperResolution:
         self._gens = None
         self._pstreams = None
         self._prep_stream = None
+        self.gated = os.environ.get("MSR_TILER_GATED", "0") != "0"
+        self._gate = None
+        self._gate_ring = 0
+        self._gate_events = [torch.cuda.Event() for _ in range(8)] if torch.cuda.is_available() else []
         self._bufs = None
         self._batches = None
         self._last = (None, 0, 0)
@@ -238,10 +242,22 @@ class DEMSuperResolution:
 
     def _make_pipeline(self) -> None:
         """`pipeline` generator handles with the same weights, each with its own stream (built once, at construction
-        when the model is a Generator)."""
+        when the model is a Generator).
+
+        HIP binds a stream to a hardware queue at its first use, in order, and queues whose ids are equal modulo 4
+        share a dispatch pipe; when two of the four busy streams of a two-handle pipeline (two call streams, two
+        auxiliary streams) share one, the pipeline runs ~9 % slower instead of ~5 % faster than one stream
+        (profiles/r02_raster_queue_pairing.txt).  So the call streams are used once here and the handles are planned
+        right after them: four consecutive queue ids."""
         self._gens = [self._gen] + [self._gen.clone() for _ in range(self.pipeline - 1)]
         with torch.cuda.device(self.device):
             self._pstreams = [torch.cuda.Stream(self.device) for _ in self._gens]
+            for st in self._pstreams:
+                with torch.cuda.stream(st):
+                    torch.zeros(1, device=self.device)
+            for g in self._gens:
+                g.prepare()
+            torch.cuda.synchronize(self.device)
 
     def patchOrigins(self, px: int, py: int) -> np.ndarray:
         """[n, 2] int32 (xx, yy) in padded coordinates, generation order (process_full_tiles.py:453-454)."""
@@ -333,6 +349,7 @@ class DEMSuperResolution:
                         ps.wait_event(buf["free"])
                     for t in (sx, sy, mm_sel):
                         t.record_stream(ps)
+                gated = self.gated and len(self._gens) > 1
                 for c in range(ncall):
                     k = c % len(self._gens)
                     with torch.cuda.stream(self._pstreams[k]):
@@ -340,7 +357,12 @@ class DEMSuperResolution:
                                                      cols, sx[c * B:].data_ptr(), sy[c * B:].data_ptr(),
                                                      mm_sel[c * B:].data_ptr(), B, batches[k].data_ptr(), self._stream())
                         _lib.raise_for(lib, h, rc, "msr_extract_patches")
-                        self._gens[k].forward_device(batches[k], out=preds[c * B:(c + 1) * B].unsqueeze(-1))
+                        self._gens[k].forward_device(batches[k], out=preds[c * B:(c + 1) * B].unsqueeze(-1),
+                                                     gate=self._gate if gated else None)
+                        if gated:
+                            self._gate_ring = (self._gate_ring + 1) % len(self._gate_events)
+                            self._gate = self._gate_events[self._gate_ring]
+                            self._gate.record(self._pstreams[k])
                 for ps in self._pstreams:
                     cur.wait_stream(ps)
                 cur.wait_event(st["event"])

@@ -118,19 +118,6 @@ def main():
             torch.zeros((len(my_rows) * T, width), dtype=torch.float32, device=dev),
             torch.zeros((len(my_rows) * T, width), dtype=torch.uint8, device=dev)]
     patches = calls = 0
-    wz = os.environ.get("MSR_RB_ZERO", "")
-    if wz == "default":
-        gen.forward_device(torch.zeros((B, S, S, 2), device="cuda"))     # warm-up: one generator call
-    elif wz == "default_rand":
-        gen.forward_device(torch.zeros((B, S, S, 2), device="cuda").uniform_(-0.5, 0.5))
-    elif wz == "side":
-        with torch.cuda.stream(dsr._pstreams[0]):
-            gen.forward_device(torch.zeros((B, S, S, 2), device="cuda"))
-        torch.cuda.synchronize()
-    elif wz == "clone_first":
-        with torch.cuda.stream(dsr._pstreams[1]):
-            dsr._gens[1].forward_device(torch.zeros((B, S, S, 2), device="cuda").uniform_(-0.5, 0.5))
-        torch.cuda.synchronize()
     if todo:
         dsr.processTile(*todo[0])                                     # and one whole tile (clone handles, streams)
     if world > 1:
@@ -144,8 +131,6 @@ def main():
             nv, nc = dsr.last_counts
             calls += nc
             patches += nv
-            if os.environ.get("MSR_RB_NOCOPY"):
-                continue
             r0 = my_rows.index(yy) * T
             prod[0][r0:r0 + T, xx:xx + T] = m
             prod[1][r0:r0 + T, xx:xx + T] = sd
