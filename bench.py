@@ -189,6 +189,12 @@ def run_workload(args, D: Dist, workload: str, precision: str, with_cpu: bool, w
             for _ in range(ns)]
     gen = gens[0]
     streams = [torch.cuda.Stream() for _ in range(ns)]
+    if ns > 1:      # call streams first, then the handles' plans: four consecutive hardware-queue ids (tiler.py _make_pipeline)
+        for st in streams:
+            with torch.cuda.stream(st):
+                torch.zeros(1, device="cuda")
+        for g in gens:
+            g.prepare()
     # a small pool of distinct synthetic batches, resident in HBM before the timed region
     pool = [torch.from_numpy(synthetic_patches(B, S, seed=1000 * rank + i)).cuda() for i in range(2)]
     outs = [torch.empty((B, S, S, 1), dtype=torch.float32, device="cuda") for _ in range(ns)]
