@@ -25,6 +25,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+// Workgroup barrier of the ping-pong kernel, spelled as what it is on gfx950: a workgroup-scope release (every LDS
+// store of this wave has completed: s_waitcnt lgkmcnt(0)), the hardware s_barrier, a workgroup-scope acquire.  That is
+// exactly what __syncthreads() lowers to, but the ping-pong schedule executes its barriers under WAVE-GROUP-dependent
+// control flow (group Y runs one barrier more at the start and one fewer at the end), which __syncthreads() — defined
+// for barriers every thread reaches at the same textual call — does not promise to support.  s_barrier itself only
+// counts arrivals: it releases when every wave of the workgroup has executed one more s_barrier, wherever that
+// instruction sits in its stream.  The counts are balanced by construction (table at the kernel).
+#define MSR_WG_BARRIER()                                       \
+    {                                                          \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
+        __builtin_amdgcn_s_barrier();                          \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
+    }
+
 // K-step = BKC channels of one tap; LDS rows are BKC + 4 floats.  Both pitches (36 and 20 floats) put the 16
 // lanes of a ds_read_b128 group on 16 distinct 16-byte slots, i.e. the fragment reads are conflict-free.
 
@@ -1073,6 +1087,9 @@ conv_igemm_bf16x3_halo(const ConvParams p, const TileGeom g) {
 // "Two waves per SIMD", items 5 and 9).  X owns the top 8 rows of a 16 x 16 pixel tile, Y the bottom 8; both use
 // the same 128-channel weight tile.  LDS: input halo (18 x 18 pixels x 32 channels) double-buffered by chunk,
 // weight tile double-buffered by K-step, 160-byte rows: 2 * 324 * 160 + 2 * 128 * 160 = 144,640 B.
+// Barrier count (s_barrier only counts arrivals; every wave must execute the same number): per K-step each wave
+// runs two (after R, after M); group Y runs one extra before its first R and skips the one after its last M of the
+// workgroup's last tile: X = 1 + 2 * steps, Y = 1 + 1 + 2 * steps - 1 — equal.  (MSR_WG_BARRIER, top of the file.)
 // Hazards (b = barrier at the end of a phase): the weights of step t+1 go to Bs[(t+1)&1] during R(t) of both
 // groups (phases 2t, 2t+1); that buffer was last read in R(t-1) (phases 2t-2, 2t-1) and is next read in R(t+1)
 // (phases 2t+2, 2t+3).  The halo of chunk c+1 goes to Ah[(c+1)&1] on tap 7 of chunk c.
@@ -1267,14 +1284,14 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
         MSR_R(T, LASTP)                                                                          \
         if ((LASTP) && (T) == 16 && EPI != EPI_PARTIAL) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0); \
         MSR_STAMP()                                                                              \
-        __syncthreads();                                                                         \
+        MSR_WG_BARRIER()                                                                         \
         MSR_STAMP()                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         MSR_M()                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         MSR_STAMP()                                                                              \
         /* Y's M on the workgroup's very last step has no partner segment */                     \
-        if (!((LASTP) && (T) == 17) || has_next || grp == 0) __syncthreads();                    \
+        if (!((LASTP) && (T) == 17) || has_next || grp == 0) MSR_WG_BARRIER()                    \
     }
 #define MSR_PAIR(LASTP)                                                                          \
     MSR_STEP(0, LASTP) MSR_STEP(1, LASTP) MSR_STEP(2, LASTP) MSR_STEP(3, LASTP) MSR_STEP(4, LASTP) \
@@ -1294,8 +1311,8 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
     MSR_WRITE_H(0);
     MSR_WRITE_B(0);
     MSR_LOAD_B(w_tile + MSR_WOFF(1));
-    __syncthreads();
-    if (grp == 1) __syncthreads();                // Y starts half a step late (phase 0 is X's R(0) alone)
+    MSR_WG_BARRIER()
+    if (grp == 1) MSR_WG_BARRIER()                // Y starts half a step late (phase 0 is X's R(0) alone)
     TileGeom ge = g;                              // the epilogue numbers its moment slabs by 8-row tiles
     ge.th_l = 3;
     ge.tiles_y = g.tiles_y * 2;

@@ -1,0 +1,39 @@
+#!/bin/bash
+# Round-2 measurement artefacts (run through gpurun from the repo root).  Outputs land in gpurun_out/collect_r02/;
+# the summaries that are judged are copied into profiles/ with an r02_ prefix.
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/collect_r02; mkdir -p $O
+# per-layer tables (known call count, one stream, launches in plan order)
+for cfg in "spade512 bf16x3" "spade512 bf16x3_gbf16" "spade256 bf16x3"; do
+  set -- $cfg; wl=$1; pr=$2; S=${wl#spade}; B=16; [ $S = 512 ] && B=8
+  rocprofv3 --kernel-trace --stats -d $O/kt_${wl}_$pr -o kt --output-format csv -- python3 profiles/run_forwards.py $wl 25 $pr > $O/kt_${wl}_$pr.log 2>&1 || exit 1
+  python profiles/analyze_trace.py $O/kt_${wl}_$pr/kt_kernel_trace.csv $S $B > $O/${wl}_${pr}_conv_layers.txt || exit 1
+  cp $O/kt_${wl}_$pr/kt_kernel_stats.csv $O/${wl}_${pr}_kernel_stats.csv
+  echo "trace $wl $pr done"
+done
+# HBM traffic of the default workload: separate PMC passes
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace -d $O/pmc_$c -o p --output-format csv -- python3 profiles/run_forwards.py spade512 3 > $O/pmc_$c.log 2>&1 || exit 1
+done
+python profiles/summarize_pmc.py $O/pmc_FETCH_SIZE/p_counter_collection.csv $O/pmc_WRITE_SIZE/p_counter_collection.csv spade512_bf16x3 $O/spade512_bf16x3_pmc_summary.json 3 > /dev/null || exit 1
+echo "pmc traffic done"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d $O/pmc_sq -o p --output-format csv -- python3 profiles/run_forwards.py spade512 3 > $O/pmc_sq.log 2>&1 || exit 1
+python profiles/pmc_util.py $O/pmc_sq/p_counter_collection.csv conv > $O/spade512_bf16x3_sq_counters.txt || exit 1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d $O/pmc_sq_gb -o p --output-format csv -- python3 profiles/run_forwards.py spade512 3 bf16x3_gbf16 > $O/pmc_sq_gb.log 2>&1 || exit 1
+python profiles/pmc_util.py $O/pmc_sq_gb/p_counter_collection.csv conv > $O/spade512_bf16x3_gbf16_sq_counters.txt || exit 1
+echo "pmc sq done"
+# the driver's own command under the kernel trace: its per-kernel averages must agree with bench.py's event timing
+rocprofv3 --kernel-trace --stats -d $O/kt_bench -o kt --output-format csv -- python3 bench.py --no-cpu-baseline --no-also > $O/kt_bench.log 2>&1 || exit 1
+cp $O/kt_bench/kt_kernel_stats.csv $O/bench_py_kernel_stats.csv
+echo "trace of bench.py done"
+python bench.py > $O/bench.json 2> $O/bench.err || exit 1
+python bench.py --streams 2 --no-cpu-baseline --no-also > $O/bench_2streams.json 2> /dev/null || exit 1
+echo "bench done"
+# tile loop: trace by kernel family (idle gaps between tiles), end to end against generator-only
+rocprofv3 --kernel-trace --stats -d $O/kt_raster -o kt --output-format csv -- python3 raster_bench.py --image-size 512 --stride 64 --batch-size 8 --no-reference > $O/kt_raster.log 2>&1 || exit 1
+python profiles/trace_families.py $O/kt_raster/kt_kernel_trace.csv 0.55 > $O/raster512_families.txt || exit 1
+python raster_bench.py > $O/raster256.json 2> /dev/null || exit 1
+python raster_bench.py --image-size 512 --stride 64 --batch-size 8 > $O/raster512.json 2> /dev/null || exit 1
+(python tests/gpu_determinism_soak.py 512 8 200 && python tests/gpu_determinism_soak.py 256 16 300) > $O/determinism_soak.txt 2>&1 || exit 1
+echo "all done"

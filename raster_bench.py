@@ -166,7 +166,16 @@ def main():
                     dsr._gens[k].forward_device(inputs[k], out=ob[k])
             torch.cuda.synchronize()
             return calls * B * (S / 512.0) ** 2 / (time.perf_counter() - tr)
-        gen_only = gen_pass([b.clone() for b in dsr._batches])
+        # a FULL batch of real patches (the loop leaves the tile's last, zero-padded batch in the buffers; zeros run at a
+        # higher clock): the first B valid patches of the first tile of the shard
+        st0 = dsr._prepare_tile(*todo[0])
+        st0["event"].synchronize()
+        real = torch.empty((B, S, S, 2), device="cuda")
+        rows_p, cols_p = dsr.dem_padded_shape
+        dsr._lib.msr_extract_patches(dsr._h, dsr.img_padded.data_ptr(), dsr.dem_padded.data_ptr(), rows_p, cols_p,
+                                     st0["sx"].data_ptr(), st0["sy"].data_ptr(), st0["mm_sel"].data_ptr(), B,
+                                     real.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        gen_only = gen_pass([real for _ in dsr._gens])
         gen_only_noise = gen_pass([torch.zeros((B, S, S, 2), device="cuda").uniform_(-0.5, 0.5) for _ in dsr._gens])
     tot = torch.tensor([patches, calls, elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
