@@ -157,6 +157,20 @@ int msr_stitch_tile(msr_handle* h, const float* pred_dev, const int32_t* key_dev
                     int32_t tile_size, int32_t stride, float no_value, int32_t as_implemented,
                     float* mean_dev, float* std_dev, uint8_t* good_dev, void* stream);
 
+/* ---- patch-row-sharded ("halo") mode: north_star's exchange of overlap halos (second mode) ------------
+ * The reference has no counterpart: it re-generates the halo patches of every tile (process_full_tiles.py:449-454).
+ * msr_stitch_partial is msr_stitch_tile stopped before the finalisation of :409-413, with the textbook (West) variance
+ * update: it returns the raw accumulators (w_sum, mean, S) [T, T] of the patches it was given, so that two ranks that
+ * each hold part of the patches covering a pixel can combine them. */
+int msr_stitch_partial(msr_handle* h, const float* pred_dev, const int32_t* key_dev, const float* dmm_dev, int32_t n,
+                       int32_t tile_size, int32_t stride, float* wsum_dev, float* mean_dev, float* s_dev, void* stream);
+/* Pairwise (Chan) combine of two sets of accumulators of the same `count` pixels — a = the rank with the earlier patch
+ * rows, b = the later one, or b == NULL — followed by rebuildTile's finalisation (good = w_sum > 0,
+ * std = sqrt(S / w_sum), no_value where not good; process_full_tiles.py:409-413). */
+int msr_halo_merge(msr_handle* h, const float* wa_dev, const float* ma_dev, const float* sa_dev, const float* wb_dev,
+                   const float* mb_dev, const float* sb_dev, int64_t count, float no_value, float* mean_dev,
+                   float* std_dev, uint8_t* good_dev, void* stream);
+
 /* Optional: replace the library's own blending window (makeGaussianKernel + 1e-7, purged S//16 per side,
  * process_full_tiles.py:347-361,391-393) by a caller-computed float64 [S-2p, S-2p] HOST array — the Python
  * host passes NumPy's own evaluation so the GPU stitcher is bit-identical to the NumPy reference. */

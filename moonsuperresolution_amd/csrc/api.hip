@@ -1492,12 +1492,9 @@ static int default_window(msr_handle* h) {
     return msr_set_blend_window(h, w.data(), ws);
 }
 
-int msr_stitch_tile(msr_handle* h, const float* pred, const int32_t* key, const float* dmm, int32_t n,
-                    int32_t tile_size, int32_t stride, float no_value, int32_t as_implemented, float* mean,
-                    float* stdv, uint8_t* good, void* stream) {
-    if (!h) return MSR_ERR_INVALID;
-    if (!mean || !stdv || !good || n < 0 || (n > 0 && (!pred || !key || !dmm)))
-        return fail(h, MSR_ERR_INVALID, "msr_stitch_tile: null pointer");
+static int stitch_impl(msr_handle* h, const float* pred, const int32_t* key, const float* dmm, int32_t n,
+                       int32_t tile_size, int32_t stride, float no_value, int32_t as_implemented, float* mean,
+                       float* stdv, uint8_t* good, float* wsum_partial, void* stream) {
     if (tile_size <= 0 || stride <= 0 || stride > h->S)
         return fail(h, MSR_ERR_INVALID, "msr_stitch_tile: tile_size %d / stride %d invalid for image_size %d", tile_size,
                     stride, h->S);
@@ -1510,7 +1507,35 @@ int msr_stitch_tile(msr_handle* h, const float* pred, const int32_t* key, const 
         h->stitch_grid_cap = NG * NG;
     }
     HIPCHK(h, launch_stitch_tile(pred, key, dmm, n, h->S, tile_size, stride, no_value, as_implemented, h->window,
-                                 h->stitch_grid, mean, stdv, good, (hipStream_t)stream));
+                                 h->stitch_grid, mean, stdv, good, (hipStream_t)stream, wsum_partial));
+    return MSR_OK;
+}
+
+int msr_stitch_tile(msr_handle* h, const float* pred, const int32_t* key, const float* dmm, int32_t n,
+                    int32_t tile_size, int32_t stride, float no_value, int32_t as_implemented, float* mean,
+                    float* stdv, uint8_t* good, void* stream) {
+    if (!h) return MSR_ERR_INVALID;
+    if (!mean || !stdv || !good || n < 0 || (n > 0 && (!pred || !key || !dmm)))
+        return fail(h, MSR_ERR_INVALID, "msr_stitch_tile: null pointer");
+    return stitch_impl(h, pred, key, dmm, n, tile_size, stride, no_value, as_implemented, mean, stdv, good, nullptr, stream);
+}
+
+int msr_stitch_partial(msr_handle* h, const float* pred, const int32_t* key, const float* dmm, int32_t n,
+                       int32_t tile_size, int32_t stride, float* wsum, float* mean, float* s_acc, void* stream) {
+    if (!h) return MSR_ERR_INVALID;
+    if (!wsum || !mean || !s_acc || n < 0 || (n > 0 && (!pred || !key || !dmm)))
+        return fail(h, MSR_ERR_INVALID, "msr_stitch_partial: null pointer");
+    return stitch_impl(h, pred, key, dmm, n, tile_size, stride, 0.f, /*as_implemented=*/0, mean, s_acc, nullptr, wsum, stream);
+}
+
+int msr_halo_merge(msr_handle* h, const float* wa, const float* ma, const float* sa, const float* wb, const float* mb,
+                   const float* sb, int64_t count, float no_value, float* mean, float* stdv, uint8_t* good,
+                   void* stream) {
+    if (!h) return MSR_ERR_INVALID;
+    if (!wa || !ma || !sa || !mean || !stdv || !good || count < 0 || (wb && (!mb || !sb)))
+        return fail(h, MSR_ERR_INVALID, "msr_halo_merge: bad argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, launch_halo_merge(wa, ma, sa, wb, mb, sb, (long)count, no_value, mean, stdv, good, (hipStream_t)stream));
     return MSR_OK;
 }
 

@@ -223,7 +223,10 @@ hipError_t launch_compact_patches(const uint8_t* valid, const int* ox, const int
                                   int* key, float* dmm, int* meta, hipStream_t s);
 hipError_t launch_stitch_tile(const float* pred, const int* key, const float* dmm, int n, int S, int T, int stride,
                               float no_value, int as_implemented, const double* window, int* grid_ws,
-                              float* mean, float* stdv, uint8_t* good, hipStream_t s);
+                              float* mean, float* stdv, uint8_t* good, hipStream_t s, float* wsum_partial = nullptr);
+hipError_t launch_halo_merge(const float* wa, const float* ma, const float* sa, const float* wb, const float* mb,
+                             const float* sb, long n, float no_value, float* mean, float* stdv, uint8_t* good,
+                             hipStream_t s);
 hipError_t launch_resize_area(const float* src, int h, int w, float* dst, int dh, int dw, int factor, hipStream_t s);
 hipError_t launch_resize_cubic(const float* src, int h, int w, float* dst, int dh, int dw, hipStream_t s);
 

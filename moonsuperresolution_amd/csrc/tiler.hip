@@ -208,7 +208,8 @@ __global__ void __launch_bounds__(256) stitch_tile_kernel(const float* __restric
                                                           const int* __restrict__ grid, int NG, int S, int T,
                                                           int stride, float no_value, int as_implemented,
                                                           const double* __restrict__ window, float* __restrict__ mean_o,
-                                                          float* __restrict__ std_o, uint8_t* __restrict__ good_o) {
+                                                          float* __restrict__ std_o, uint8_t* __restrict__ good_o,
+                                                          float* __restrict__ wsum_o) {
     const int tx = blockIdx.x * 16 + (threadIdx.x & 15);
     const int ty = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (tx >= T || ty >= T) return;
@@ -238,9 +239,13 @@ __global__ void __launch_bounds__(256) stitch_tile_kernel(const float* __restric
             mean = mean_new;
         }
     }
+    const size_t o = (size_t)ty * T + tx;
+    if (wsum_o) {      // halo mode: the raw accumulators (w_sum, mean, S) of this rank's patches, merged later
+        wsum_o[o] = w_sum; mean_o[o] = mean; std_o[o] = s_acc;
+        return;
+    }
     const bool good = w_sum > 0.f;                                                           // :409
     const float sd = sqrtf(s_acc / w_sum);                                                   // :411
-    const size_t o = (size_t)ty * T + tx;
     mean_o[o] = good ? mean : no_value;
     std_o[o] = good ? sd : no_value;
     good_o[o] = good ? 1 : 0;
@@ -248,14 +253,60 @@ __global__ void __launch_bounds__(256) stitch_tile_kernel(const float* __restric
 
 hipError_t launch_stitch_tile(const float* pred, const int* key, const float* dmm, int n, int S, int T, int stride,
                               float no_value, int as_implemented, const double* window, int* grid_ws, float* mean,
-                              float* stdv, uint8_t* good, hipStream_t s) {
+                              float* stdv, uint8_t* good, hipStream_t s, float* wsum_partial) {
     const int NG = (T + S - 1) / stride;   // len(range(0, T + S - stride, stride))
     hipError_t e = hipMemsetAsync(grid_ws, 0xFF, sizeof(int) * NG * NG, s);
     if (e != hipSuccess) return e;
     if (n > 0) stitch_grid_kernel<<<(n + 255) / 256, 256, 0, s>>>(key, n, stride, NG, grid_ws);
     stitch_tile_kernel<<<dim3((T + 15) / 16, (T + 15) / 16), 256, 0, s>>>(pred, dmm, grid_ws, NG, S, T, stride,
                                                                          no_value, as_implemented, window, mean,
-                                                                         stdv, good);
+                                                                         stdv, good, wsum_partial);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// halo_merge: the exchange step of the patch-row-sharded ("halo") mode.  Two ranks hold, for the same output
+// pixels, the weighted-Welford accumulators (w_sum, mean, S) of their own patches (stitch_tile with partial output,
+// textbook West S); the pairwise combine (Chan et al.) of a = the lower rank's (earlier patches) and b = the upper
+// rank's gives the accumulators of the union:
+//     w = wa + wb,  d = mb - ma,  mean = ma + d * wb / w,  S = Sa + Sb + d^2 * wa * wb / w
+// evaluated in float64, then finalised like rebuildTile (process_full_tiles.py:409-413): good = w > 0,
+// std = sqrt(S / w), no_value where not good.  b == nullptr finalises a alone.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) halo_merge_kernel(const float* __restrict__ wa, const float* __restrict__ ma,
+                                                         const float* __restrict__ sa, const float* __restrict__ wb,
+                                                         const float* __restrict__ mb, const float* __restrict__ sb,
+                                                         long n, float no_value, float* __restrict__ mean_o,
+                                                         float* __restrict__ std_o, uint8_t* __restrict__ good_o) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        double w = wa[i], m = ma[i], S = sa[i];
+        if (wb) {
+            const double w2 = wb[i];
+            if (w2 > 0.0) {
+                if (w > 0.0) {
+                    const double d = (double)mb[i] - m, wt = w + w2;
+                    S = S + (double)sb[i] + d * d * (w * w2 / wt);
+                    m = m + d * (w2 / wt);
+                    w = wt;
+                } else {
+                    w = w2; m = mb[i]; S = sb[i];
+                }
+            }
+        }
+        const bool good = w > 0.0;
+        mean_o[i] = good ? (float)m : no_value;
+        std_o[i] = good ? sqrtf((float)S / (float)w) : no_value;
+        good_o[i] = good ? 1 : 0;
+    }
+}
+
+hipError_t launch_halo_merge(const float* wa, const float* ma, const float* sa, const float* wb, const float* mb,
+                             const float* sb, long n, float no_value, float* mean, float* stdv, uint8_t* good,
+                             hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    long blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    halo_merge_kernel<<<(int)blocks, 256, 0, s>>>(wa, ma, sa, wb, mb, sb, n, no_value, mean, stdv, good);
     return hipGetLastError();
 }
 

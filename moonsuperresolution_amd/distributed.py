@@ -99,3 +99,66 @@ def process_map_sharded(shape: Tuple[int, int], tile_size: int, tiles: Sequence[
                 f[r0:r0 + t.shape[0]] = t
         mean, std, good = full
     return tuple(t[:h, :w].cpu().numpy() for t in (mean, std, good))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Patch-row-sharded ("halo") mode: the exchange step (moonsuperresolution_amd/halo.py holds the GPU side)
+# ----------------------------------------------------------------------------------------------------------------
+def exchange_halo(send_down, send_up, recv_down_shape, recv_up_shape, rank: int, world: int):
+    """Neighbour exchange of the boundary-zone accumulators: every rank sends `send_down` to rank - 1 and `send_up` to
+    rank + 1 and receives tensors of the given shapes from them (None at the ends of the chain).  Point-to-point
+    send / recv over the process group — RCCL on device tensors (xGMI is point-to-point: neighbour traffic needs no
+    ring collective), gloo on host tensors in the CPU tests.  Returns (from_down, from_up)."""
+    import torch
+    import torch.distributed as dist
+    ops, from_down, from_up = [], None, None
+    like = send_down if send_down is not None else send_up
+    if rank > 0:
+        from_down = torch.empty(recv_down_shape, dtype=like.dtype, device=like.device)
+        ops.append(dist.P2POp(dist.isend, send_down.contiguous(), rank - 1))
+        ops.append(dist.P2POp(dist.irecv, from_down, rank - 1))
+    if rank < world - 1:
+        from_up = torch.empty(recv_up_shape, dtype=like.dtype, device=like.device)
+        ops.append(dist.P2POp(dist.isend, send_up.contiguous(), rank + 1))
+        ops.append(dist.P2POp(dist.irecv, from_up, rank + 1))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return from_down, from_up
+
+
+def all_gather_var_rows(local, counts: Sequence[int]):
+    """All-gather of row slabs whose row counts differ by rank (halo mode: ownership boundaries follow patch rows, not
+    tiles): pad to the largest count, one all_gather_into_tensor, trim.  counts[r] = rows of rank r."""
+    import torch
+    import torch.distributed as dist
+    world = len(counts)
+    mx = max(counts)
+    block = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    block[:local.shape[0]] = local
+    out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, block)
+    return torch.cat([out[r * mx:r * mx + counts[r]] for r in range(world)], dim=0)
+
+
+def halo_zone_rows(ys: Sequence[int], image_size: int, world: int):
+    """Geometry of the halo mode for patch-row origins `ys` (sorted, padded-canvas coordinates) split over `world`
+    ranks: per rank (g0, g1) = its block of patch rows, (touch_lo, touch_hi) = the canvas rows its own patches reach
+    (purged by S // 16 per side, like rebuildTile), (own_lo, own_hi) = the canvas rows it finalises.  Ownership passes
+    from rank r - 1 to rank r at the centre of rank r's first patch row."""
+    S, p = image_size, image_size // 16
+    n = len(ys)
+    out = []
+    for r in range(world):
+        g0, g1 = rows_of_rank(n, r, world)
+        g1 = g0 + g1
+        if g1 <= g0:
+            raise ValueError("halo mode: more ranks than patch rows")
+        out.append(dict(g0=g0, g1=g1, touch_lo=ys[g0] + p, touch_hi=ys[g1 - 1] + S - p))
+    for r in range(world):
+        out[r]["own_lo"] = 0 if r == 0 else ys[out[r]["g0"]] + S // 2
+        out[r]["own_hi"] = None if r == world - 1 else ys[out[r + 1]["g0"]] + S // 2
+    for r in range(world):       # a pixel may combine at most two ranks: every block must span a whole overlap
+        if r + 2 < world and out[r]["touch_hi"] > out[r + 2]["touch_lo"]:
+            raise ValueError("halo mode: too few patch rows per rank (a pixel would need three ranks)")
+    return out

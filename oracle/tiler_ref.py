@@ -182,3 +182,118 @@ def process_map(img: np.ndarray, dem: np.ndarray, model: Callable = identity_mod
             canvas[yy:yy + tile_size, xx:xx + tile_size] = part
     h, w = dem.shape
     return tuple(c[:h, :w] for c in full)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Patch-row-sharded ("halo") mode — NOT in the reference (it re-generates the halo patches of every tile,
+# process_full_tiles.py:449-454); BASELINE.json's north_star asks for it as the multi-GPU optimisation: every patch
+# position of the raster is generated ONCE, ranks own contiguous blocks of patch rows, and the pixels near a block
+# boundary combine the weighted-Welford accumulators of the two neighbouring ranks.  This restatement
+# is the checker of moonsuperresolution_amd/halo.py.  Deviations from the reference, by construction:
+#   (1) batches are cut from a rank's patch rows, not per tile -> other SPADE batch statistics (process_full_tiles.py
+#       :462-474 vs spade.py:21): results differ beyond rounding for a real generator, not at all for the identity model;
+#   (2) the variance uses the textbook West update (S += w (x - mean_old)(x - mean_new)), because the reference's
+#       aliased form (:400-402) has no pairwise combine;
+#   (3) pixels in a boundary zone are combined pairwise (Chan) instead of sequentially: float32 rounding differs.
+# ----------------------------------------------------------------------------------------------------------------
+def halo_grid(dem_shape, image_size: int, stride: int, tile_size: int):
+    """The unique patch origins (padded-canvas coordinates) the reference's tiles touch: sorted ys, sorted xs."""
+    ys, xs = set(), set()
+    span = tile_size + image_size - stride
+    for px, py in tile_list(dem_shape, tile_size):
+        ys.update(range(py, py + span, stride))
+        xs.update(range(px, px + span, stride))
+    return sorted(ys), sorted(xs)
+
+
+def halo_rows_of_rank(n_rows: int, rank: int, world: int):
+    base, extra = divmod(n_rows, world)
+    g0 = rank * base + min(rank, extra)
+    return g0, g0 + base + (1 if rank < extra else 0)
+
+
+def halo_partials(img_p, dem_p, ys, xs, model: Callable, image_size: int, stride: int, batch_size: int,
+                  no_value: float):
+    """Accumulators (w_sum, mean, S), float32 canvas-sized, of the patches at rows `ys` (generation order: y outer, x
+    inner; batches of `batch_size` over the valid ones, the last zero-padded) — West's weighted incremental update in
+    the dtypes of rebuildTile (window float64, accumulators float32)."""
+    S = image_size
+    generated, minmax = {}, {}
+    batch, index = [], []
+    for yy in ys:
+        for xx in xs:
+            valid, ip, dp = get_patch(img_p, dem_p, xx, yy, S, no_value)
+            if not valid:
+                continue
+            patch, mm = normalize(ip, dp)
+            minmax[(xx, yy)] = mm
+            batch.append(patch)
+            index.append((xx, yy))
+            if len(batch) == batch_size:
+                run_batch(model, batch, index, generated)
+                batch, index = [], []
+    if batch:
+        while len(batch) < batch_size:
+            batch.append(np.zeros([S, S, 2]))
+            index.append((-1, -1))
+        run_batch(model, batch, index, generated)
+    hp, wp = dem_p.shape
+    w_sum = np.zeros((hp, wp), np.float32)
+    mean = np.zeros((hp, wp), np.float32)
+    s_acc = np.zeros((hp, wp), np.float32)
+    w = blend_window(S)
+    p = S // 16
+    for (kx, ky), pred in generated.items():
+        lo, hi = minmax[(kx, ky)]
+        x = (pred * (hi - lo) + lo)[p:-p, p:-p]
+        sl = (slice(ky + p, ky + S - p), slice(kx + p, kx + S - p))
+        w_sum[sl] += w
+        old = mean[sl].copy()
+        mean[sl] = old + (w / w_sum[sl]) * (x - old)
+        s_acc[sl] += w * (x - old) * (x - mean[sl])
+    return w_sum, mean, s_acc
+
+
+def chan_merge(a, b):
+    """Pairwise combine of two accumulator triples (a = earlier patches), float64 evaluation, float32 result."""
+    wa, ma, sa = (np.asarray(t, np.float64) for t in a)
+    wb, mb, sb = (np.asarray(t, np.float64) for t in b)
+    w = wa + wb
+    with np.errstate(invalid="ignore", divide="ignore"):
+        d = mb - ma
+        m = np.where(wb > 0, np.where(wa > 0, ma + d * (wb / w), mb), ma)
+        s = np.where(wb > 0, np.where(wa > 0, sa + sb + d * d * (wa * wb / w), sb), sa)
+    return w.astype(np.float32), m.astype(np.float32), s.astype(np.float32)
+
+
+def halo_finalize(acc, no_value: float):
+    w_sum, mean, s_acc = acc
+    good = w_sum > 0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        std = np.sqrt(s_acc / w_sum)
+    mean = np.where(good, mean, np.float32(no_value)).astype(np.float32)
+    std = np.where(good, std, np.float32(no_value)).astype(np.float32)
+    return mean, std, good.astype(np.uint8)
+
+
+def halo_boundaries(ys, image_size: int, world: int):
+    """Canvas row where ownership passes from rank r-1 to rank r: the centre of rank r's first patch row."""
+    return [ys[halo_rows_of_rank(len(ys), r, world)[0]] + image_size // 2 for r in range(1, world)]
+
+
+def process_map_halo(img: np.ndarray, dem: np.ndarray, model: Callable = identity_model, image_size: int = 256,
+                     stride: int = 32, batch_size: int = 16, tile_size: int = 1024, no_value: float = -32768.0,
+                     world: int = 1):
+    """The halo mode on `world` simulated ranks: per-rank accumulators, pairwise combine in rank order, finalise,
+    crop to the input extent (final pixel (y, x) = canvas pixel (y + S - s, x + S - s))."""
+    img_p, dem_p = pad_inputs(img, dem, image_size, stride, no_value)
+    ys, xs = halo_grid(dem.shape, image_size, stride, tile_size)
+    acc = None
+    for r in range(world):
+        g0, g1 = halo_rows_of_rank(len(ys), r, world)
+        part = halo_partials(img_p, dem_p, ys[g0:g1], xs, model, image_size, stride, batch_size, no_value)
+        acc = part if acc is None else chan_merge(acc, part)
+    mean, std, good = halo_finalize(acc, no_value)
+    halo = image_size - stride
+    h, w = dem.shape
+    return tuple(t[halo:halo + h, halo:halo + w] for t in (mean, std, good))

@@ -68,3 +68,73 @@ def test_uneven_rows_three_ranks_layout():
             a += p
     for a, f in zip(acc, full):
         assert np.array_equal(a, f)
+
+
+# ---- halo mode: the neighbour exchange and the variable-row gather over gloo, on the oracle's accumulators ----
+def _halo_worker(rank, world, port, q):
+    from oracle import tiler_ref
+    from moonsuperresolution_amd.distributed import all_gather_var_rows, exchange_halo, halo_zone_rows
+    from tests.helpers import synthetic_raster
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    S, s, B, T, noval = 64, 16, 4, 128, -32768.0
+    img, dem = synthetic_raster(260, 150, 31, hole=(100, 130, 40, 90))
+    model = lambda x, training=False: np.asarray(x, np.float32)   # noqa: E731
+    img_p, dem_p = tiler_ref.pad_inputs(img, dem, S, s, noval)
+    ys, xs = tiler_ref.halo_grid(dem.shape, S, s, T)
+    zones = halo_zone_rows(ys, S, world)
+    z = zones[rank]
+    hp, wp = dem_p.shape
+    own_lo, own_hi = z["own_lo"], hp if z["own_hi"] is None else z["own_hi"]
+    acc = np.stack(tiler_ref.halo_partials(img_p, dem_p, ys[z["g0"]:z["g1"]], xs, model, S, s, B, noval))   # [3, hp, wp]
+    lo, hi = z["touch_lo"], z["touch_hi"]
+    send_down = torch.from_numpy(acc[:, lo:own_lo].copy()) if rank > 0 else None
+    send_up = torch.from_numpy(acc[:, own_hi:hi].copy()) if rank < world - 1 else None
+    down_rows = zones[rank - 1]["touch_hi"] - own_lo if rank > 0 else 0
+    up_rows = own_hi - zones[rank + 1]["touch_lo"] if rank < world - 1 else 0
+    from_down, from_up = exchange_halo(send_down, send_up, (3, down_rows, wp), (3, up_rows, wp), rank, world)
+    mine = [a[own_lo:own_hi].copy() for a in acc]
+    if from_down is not None:
+        m = tiler_ref.chan_merge(tuple(from_down.numpy()), tuple(a[:down_rows] for a in mine))
+        for a, b in zip(mine, m):
+            a[:down_rows] = b
+    if from_up is not None:
+        n = own_hi - own_lo
+        m = tiler_ref.chan_merge(tuple(a[n - up_rows:] for a in mine), tuple(from_up.numpy()))
+        for a, b in zip(mine, m):
+            a[n - up_rows:] = b
+    out = tiler_ref.halo_finalize(mine, noval)
+    counts = [(hp if zz["own_hi"] is None else zz["own_hi"]) - zz["own_lo"] for zz in zones]
+    full = [all_gather_var_rows(torch.from_numpy(np.ascontiguousarray(o)), counts).numpy() for o in out]
+    halo = S - s
+    h, w = dem.shape
+    q.put((rank, [f[halo:halo + h, halo:halo + w].copy() for f in full]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_exchange_over_gloo_equals_oracle(world):
+    """exchange_halo (send / recv of the boundary zones) + all_gather_var_rows on `world` gloo ranks reproduce the
+    oracle's halo mode run in one process with the same number of simulated ranks, bit for bit."""
+    from oracle import tiler_ref
+    from tests.helpers import synthetic_raster
+    img, dem = synthetic_raster(260, 150, 31, hole=(100, 130, 40, 90))
+    model = lambda x, training=False: np.asarray(x, np.float32)   # noqa: E731
+    ref = tiler_ref.process_map_halo(img, dem, model, 64, 16, 4, 128, -32768.0, world=world)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        for a, b in zip(results[r], ref):
+            assert np.array_equal(a, b, equal_nan=True)

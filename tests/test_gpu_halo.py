@@ -1,0 +1,94 @@
+"""GPU (-m gpu): the patch-row-sharded ("halo") mode (moonsuperresolution_amd/halo.py) against its NumPy restatement
+(oracle/tiler_ref.py::process_map_halo) and against the reference-identical tile mode.
+
+What is compared with what, and to which tolerance:
+  * identity model, one rank: the mean equals the TILE mode's mean bit for bit (every pixel sees the same patches in
+    the same order; only the batch cut differs, which the identity model does not feel); std equals the oracle's
+    textbook-West std bit for bit (NaN where float32 rounding drives S below zero, as NumPy does);
+  * identity model, 2 and 3 simulated ranks (accumulate per rank, hand the boundary zones over in-process, finish):
+    bit-exact against the oracle run with the same number of ranks; <= 1e-6 relative against one rank (pairwise
+    instead of sequential combination in the zones);
+  * HIP generator: <= 1e-3 of the DEM span against the oracle's halo mode driven by the oracle generator; the distance
+    to the tile mode (other batch mates in SPADE's batch statistics) is printed — it is the mode's documented deviation.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tiler_ref
+from tests.helpers import synthetic_raster
+
+pytestmark = pytest.mark.gpu
+NOVAL = -32768.0
+
+
+def f32_identity(x, training=False):
+    return np.asarray(x, np.float32)
+
+
+def run_halo(d, img, dem, world):
+    """`world` ranks simulated on one GPU: phase 1 per rank, the zone hand-over done in-process, phase 2 per rank."""
+    d.setImages(img, dem)
+    states = [d.haloAccumulate(r, world) for r in range(world)]
+    slabs = []
+    for r, st in enumerate(states):
+        from_down = states[r - 1]["send_up"] if r > 0 else None
+        from_up = states[r + 1]["send_down"] if r < world - 1 else None
+        assert from_down is None or tuple(from_down.shape) == (3, st["down_rows"], st["wp"])
+        assert from_up is None or tuple(from_up.shape) == (3, st["up_rows"], st["wp"])
+        slabs.append(d.haloFinish(st, from_down, from_up))
+    assert slabs[0][1][0] == 0 and all(slabs[i][1][1] == slabs[i + 1][1][0] for i in range(world - 1))
+    return d.cropHalo(slabs)
+
+
+@pytest.mark.parametrize("S,stride,B,T,shape,hole", [
+    (64, 16, 4, 128, (200, 330), (90, 110, 140, 170)),
+    (64, 8, 16, 64, (150, 100), (20, 60, 40, 70)),
+    (128, 32, 5, 256, (300, 280), None),
+])
+def test_identity_model_halo_mode(hip_lib, S, stride, B, T, shape, hole):
+    from moonsuperresolution_amd import DSRConfig, HaloShardedSuperResolution
+    img, dem = synthetic_raster(shape[0], shape[1], seed=S + stride, hole=hole)
+    cfg = DSRConfig(image_size=S, stride=stride, batch_size=B, tile_size=T)
+    d = HaloShardedSuperResolution(cfg, model=f32_identity)
+    tile_mean, _, tile_good = d.processMap(img, dem)                     # the reference-identical mode
+    one = run_halo(d, img, dem, 1)
+    ref1 = tiler_ref.process_map_halo(img, dem, f32_identity, S, stride, B, T, NOVAL, world=1)
+    assert np.array_equal(one[2], tile_good) and np.array_equal(one[0], tile_mean)
+    for a, b in zip(one, ref1):
+        assert np.array_equal(a, b, equal_nan=True)
+    ok = one[2] == 1
+    for world in (2, 3):
+        got = run_halo(d, img, dem, world)
+        ref = tiler_ref.process_map_halo(img, dem, f32_identity, S, stride, B, T, NOVAL, world=world)
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b, equal_nan=True), world
+        assert np.array_equal(got[2], one[2])
+        scale = float(np.abs(one[0][ok]).max())
+        assert float(np.abs(got[0][ok] - one[0][ok]).max()) <= 1e-6 * scale
+    d.close()
+
+
+def test_generator_halo_mode_vs_oracle_and_tile_mode(hip_lib):
+    from moonsuperresolution_amd import DSRConfig, Generator, HaloShardedSuperResolution, make_weights
+    from oracle import generator_ref
+    w = make_weights("gaugan_no_kl", 64, seed=1234, bias_scale=0.05)
+    img, dem = synthetic_raster(150, 140, 9)
+    cfg = DSRConfig(image_size=64, stride=16, batch_size=4, tile_size=128)
+    gen = Generator(64, 4, variant="gaugan_no_kl", weights=w)
+    d = HaloShardedSuperResolution(cfg, model=gen)
+    tile_mean, tile_std, tile_good = d.processMap(img, dem)
+    got = run_halo(d, img, dem, 2)
+    wt = {k: torch.from_numpy(v) for k, v in w.items()}
+    ref = tiler_ref.process_map_halo(
+        img, dem, lambda x, training=False: generator_ref.spade_call(x, wt, "gaugan_no_kl", dtype=torch.float32),
+        64, 16, 4, 128, NOVAL, world=2)
+    assert np.array_equal(got[2], ref[2]) and np.array_equal(got[2], tile_good) and got[2].any()
+    ok = got[2] == 1
+    span = float(dem.max() - dem.min())
+    assert np.abs(got[0][ok] - ref[0][ok]).max() <= 1e-3 * span
+    assert np.nanmax(np.abs(got[1][ok] - ref[1][ok])) <= 1e-3 * span
+    dev = float(np.abs(got[0][ok] - tile_mean[ok]).max() / span)
+    print(f"halo mode vs tile mode (other batch composition): max |mean difference| = {dev:.3e} of the DEM span")
+    assert dev < 0.5           # same picture, different batch statistics: a loose sanity bound, not a parity claim
+    d.close(); gen.close()
