@@ -53,11 +53,13 @@ WORKLOADS = {
 }
 # MI355X_MICROARCH.md: dense MFMA peaks.  For bf16x3 every algorithmic product costs three bf16 MFMA products, so
 # the algorithmic ceiling is a third of the bf16 peak; `achieved` stays ALGORITHMIC FLOP/s in every mode.
-PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16x3_gbf16": 2500.0}
+PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16x3_gbf16": 2500.0, "fp8": 5000.0}
 # MFMA products per algorithmic product; the opt-in mode runs 2 in the gamma|beta convs (half of the FLOPs), 3 elsewhere
-MFMA_PER_PRODUCT = {"fp32": 1, "bf16x3": 3, "bf16x3_gbf16": 2.5}
+MFMA_PER_PRODUCT = {"fp32": 1, "bf16x3": 3, "bf16x3_gbf16": 2.5, "fp8": 1}
 DTYPE = {"fp32": "f32", "bf16x3": "bf16x3 (f32 in/out/accumulate)",
-         "bf16x3_gbf16": "bf16x3, gamma|beta convs f16x2 (opt-in; f32 in/out/accumulate; 2-5e-4 rel L-inf, inside the 1e-3 bar)"}
+         "bf16x3_gbf16": "bf16x3, gamma|beta convs f16x2 (opt-in; f32 in/out/accumulate; 2-5e-4 rel L-inf, inside the 1e-3 bar)",
+         "fp8": "fp8 e4m3 weights x bf8 e5m2 activations in the chip-filling convs, bf16x3 elsewhere (DECLARED NON-PARITY: "
+                "BASELINE configs[4]; f32 in/out/accumulate; error stated in tests/test_gpu_baseline_configs.py)"}
 
 
 def host_threads() -> int:
@@ -299,7 +301,7 @@ def run_workload(args, D: Dist, workload: str, precision: str, with_cpu: bool, w
     if world > 1:
         res["exchange"] = {"collective": f"all_gather_into_tensor x3 ({D.backend}) of the finished rows, inside the timed region",
                            "bytes_per_rank": n_blocks * T * width * 9, "seconds_rank0": t_gather}
-    kname = "conv_igemm_f32" if precision == "fp32" else "conv_igemm_bf16x3"
+    kname = "conv_igemm_f32" if precision == "fp32" else "conv_igemm_bf16x3"      # the library names the family by its base mode
     conv = stats.get(kname)
     if conv and conv_union_ms > 0:
         ach = conv["flops"] / (conv_union_ms * 1e-3) / 1e12
@@ -395,7 +397,7 @@ def main():
                        with_b1=solo and not args.no_also)
     if solo and not args.no_also:
         also = {}
-        for wl, prec in (("spade512", "bf16x3_gbf16"), ("spade256", "bf16x3"), ("spade256", "fp32")):
+        for wl, prec in (("spade512", "bf16x3_gbf16"), ("spade512", "fp8"), ("spade256", "bf16x3"), ("spade256", "fp32")):
             if (wl, prec) == (args.workload, args.precision):
                 continue
             r = run_workload(args, D, wl, prec, with_cpu=False, with_b1=False)

@@ -61,6 +61,7 @@ struct msr_handle {
     int S = 0, B = 0, L = 0, variant = 0;
     int prec = 0;                                // PREC_F32 or PREC_BF16X3 (cfg.flags & MSR_FLAG_BF16X3)
     bool gb_f16x2 = false;                       // MSR_FLAG_GB_F16X2: 2-term fp16 products in the gamma|beta convs
+    bool fp8 = false;                            // MSR_FLAG_FP8: declared non-parity mode (fp8 weights x bf8 activations)
     std::string err;
     std::vector<WeightSpec> specs;
     std::map<std::string, int> spec_index;
@@ -291,6 +292,52 @@ int upload_conv_weight(msr_handle* h, const std::string& key, const float* host,
 struct ConvVariant { int tile; int wt_frag; int ksplit; };   // ksplit 0: conv_pick_ksplit decides (small tiles)
 ConvVariant pick_conv_variant(int B, int rout, int N, int stride, int epi, int prec, int cin);
 
+// MSR_FLAG_FP8: a 3x3 stride-1 conv runs the fp8 form of the persistent ping-pong kernel when it fills the chip with
+// whole tiles (B * (r/16)^2 * (N/128) >= 256, no K split); its input then holds one byte per channel, padded to a
+// multiple of 256 channels (two 128-byte chunks: the kernel's unrolled chunk pair).
+bool conv_fills_pp(int B, int rout, int N) {
+    return rout >= 16 && N % 128 == 0 && (long)B * (rout / 16) * (rout / 16) * (N / 128) >= 256;
+}
+int fp8_pad(int cin) { return cin < 256 ? 256 : (cin + 255) / 256 * 256; }
+// gamma|beta conv of a SPADE layer normalising C channels at resolution r
+bool gb_uses_fp8(msr_handle* h, int rout, int C) { return h->fp8 && conv_fills_pp(h->B, rout, 2 * C); }
+// main conv cin -> cout fed by that SPADE layer (its producer must be a whole-tile ping-pong launch too: its epilogue
+// is the one that writes bf8)
+bool main_uses_fp8(msr_handle* h, int rout, int cin, int cout) {
+    return h->fp8 && conv_fills_pp(h->B, rout, cout) && conv_fills_pp(h->B, rout, 2 * cin);
+}
+
+int upload(msr_handle* h, const std::string& key, const float* host, size_t floats);
+// fp8 e4m3 image of [taps][N][Cin] weights: bytes [taps][N][fp8_pad(Cin)] (zero padded), a power-of-two scale per output
+// channel chosen so that the largest |w| of the channel lands in e4m3's top binade, its e8m0 exponent replicated in
+// the four bytes of key + ".wexp"[n]
+int upload_conv_weight_fp8(msr_handle* h, const std::string& key, const float* host, int taps, int N, int Cin) {
+    const int cp = fp8_pad(Cin);
+    std::vector<unsigned char> q((size_t)taps * N * cp, 0);
+    std::vector<int> wexp(N);
+    for (int n = 0; n < N; ++n) {
+        float amax = 0.f;
+        for (int t = 0; t < taps; ++t)
+            for (int k = 0; k < Cin; ++k) amax = std::max(amax, std::fabs(host[((size_t)t * N + n) * Cin + k]));
+        int e = 0;
+        if (amax > 0.f) {
+            int fe;
+            (void)std::frexp(amax / 448.f, &fe);      // amax / 448 = m * 2^fe, m in [0.5, 1): 2^fe >= amax / 448
+            e = fe;
+        }
+        e = std::max(-100, std::min(100, e));
+        const float inv = std::ldexp(1.f, -e);
+        for (int t = 0; t < taps; ++t)
+            for (int k = 0; k < Cin; ++k)
+                q[((size_t)t * N + n) * cp + k] = msr_f32_to_e4m3(host[((size_t)t * N + n) * Cin + k] * inv);
+        const unsigned b = (unsigned)(127 + e);
+        wexp[n] = (int)(b | (b << 8) | (b << 16) | (b << 24));
+    }
+    int rc = upload(h, key, reinterpret_cast<const float*>(q.data()), q.size() / 4);
+    if (rc) return rc;
+    return upload(h, key + ".wexp", reinterpret_cast<const float*>(wexp.data()), wexp.size());
+}
+
 // Output resolution of the conv a weight belongs to ("enc.ds3.kernel" -> S>>3, "gen.rb4...." -> sw<<3).
 bool weight_conv_shape(msr_handle* h, const std::string& name, int* rout, int* stride) {
     int i = 0;
@@ -387,6 +434,9 @@ int msr_create(const msr_config* cfg, msr_handle** out) {
     h->gb_f16x2 = h->prec == PREC_BF16X3 && (cfg->flags & MSR_FLAG_GB_F16X2);
     if ((cfg->flags & MSR_FLAG_GB_F16X2) && !(cfg->flags & MSR_FLAG_BF16X3))
         return fail(nullptr, MSR_ERR_INVALID, "MSR_FLAG_GB_F16X2 needs MSR_FLAG_BF16X3");
+    if ((cfg->flags & MSR_FLAG_FP8) && (!(cfg->flags & MSR_FLAG_BF16X3) || (cfg->flags & MSR_FLAG_GB_F16X2)))
+        return fail(nullptr, MSR_ERR_INVALID, "MSR_FLAG_FP8 goes with MSR_FLAG_BF16X3 alone (the layers it does not cover run bf16x3)");
+    h->fp8 = (cfg->flags & MSR_FLAG_FP8) && cfg->variant != MSR_PIX2PIX;
     if (cfg->variant == MSR_PIX2PIX) { h->prec = PREC_F32; h->gb_f16x2 = false; }   // the parity config runs on the fp32 MFMA
     build_specs(h.get());
     *out = h.release();
@@ -551,8 +601,10 @@ int msr_load_weight(msr_handle* h, const char* name_c, const float* host, const 
             hwio_to_tap_oc_ic(host, img.data(), 9, cin, C, 2 * C, rowmap.data());
             int rout = 0, stride = 1;
             weight_conv_shape(h, name, &rout, &stride);
-            rc = upload_conv_weight(h, base + ".gb.kernel", img.data(), img.size(), 9, 2 * C, cin,
-                                    weight_uses_frag(h, name, 2 * C, EPI_SPADE, cin), gb_uses_f16x2(h, rout, 2 * C, cin));
+            if (gb_uses_fp8(h, rout, C)) rc = upload_conv_weight_fp8(h, base + ".gb.kernel", img.data(), 9, 2 * C, cin);
+            else
+                rc = upload_conv_weight(h, base + ".gb.kernel", img.data(), img.size(), 9, 2 * C, cin,
+                                        weight_uses_frag(h, name, 2 * C, EPI_SPADE, cin), gb_uses_f16x2(h, rout, 2 * C, cin));
         }
     } else if (ends_with(name, ".conv_gamma.bias") || ends_with(name, ".conv_beta.bias")) {
         const bool is_beta = ends_with(name, ".conv_beta.bias");
@@ -567,7 +619,11 @@ int msr_load_weight(msr_handle* h, const char* name_c, const float* host, const 
         const int taps = (int)(s[0] * s[1]), cin = (int)s[2], cout = (int)s[3];
         std::vector<float> t(count);
         hwio_to_tap_oc_ic(host, t.data(), taps, cin, cout, cout, nullptr);
-        rc = upload_conv_weight(h, name, t.data(), count, taps, cout, cin, weight_uses_frag(h, name, cout, EPI_BIAS, cin));
+        int rout = 0, stride = 1;
+        if (name.rfind("gen.rb", 0) == 0 && weight_conv_shape(h, name, &rout, &stride) && main_uses_fp8(h, rout, cin, cout))
+            rc = upload_conv_weight_fp8(h, name, t.data(), taps, cout, cin);
+        else
+            rc = upload_conv_weight(h, name, t.data(), count, taps, cout, cin, weight_uses_frag(h, name, cout, EPI_BIAS, cin));
     } else {
         rc = upload(h, name, host, count);
     }
@@ -787,18 +843,22 @@ int plan_spade(msr_handle* h) {
                                    int res_shift, bool want_stats) -> int {
             char k[160];
             Padded hb, ab;
-            snprintf(k, sizeof k, "ws.gen.rb%d.h%d", i, j); int rc2 = alloc_padded(h, k, r, 128, &hb); if (rc2) return rc2;
-            snprintf(k, sizeof k, "ws.gen.rb%d.a%d", i, j); rc2 = alloc_padded(h, k, r, C, &ab); if (rc2) return rc2;
+            // MSR_FLAG_FP8: tensors that feed an fp8 conv hold one byte per channel, padded to 256 channels; the kernels
+            // address them in float slots of 4 channels
+            const bool gb8 = gb_uses_fp8(h, r, C), cv8 = main_uses_fp8(h, r, C, f);
+            const int hslots = gb8 ? fp8_pad(128) / 4 : 128, aslots = cv8 ? fp8_pad(C) / 4 : C;
+            snprintf(k, sizeof k, "ws.gen.rb%d.h%d", i, j); int rc2 = alloc_padded(h, k, r, hslots, &hb); if (rc2) return rc2;
+            snprintf(k, sizeof k, "ws.gen.rb%d.a%d", i, j); rc2 = alloc_padded(h, k, r, aslots, &ab); if (rc2) return rc2;
             Op em; em.type = OP_SMALLCIN; em.src_is_input = true;
             SmallCinParams& p = em.sc;
             snprintf(k, sizeof k, "gen.rb%d.spade_%d.conv.kernel", i, j); p.w = need(k);
             snprintf(k, sizeof k, "gen.rb%d.spade_%d.conv.bias", i, j); p.bias = need(k);
             p.out = hb.base; p.B = B; p.S = S; p.Hout = r; p.Cout = 128;
             p.ay = 1; p.cy = -1; p.lim = r; p.f = S / r; p.o = (S / r) / 2;
-            p.out_px = 128; p.out_py = hb.py(); p.out_pb = hb.pb(); p.out_off = hb.interior();
+            p.out_px = hslots; p.out_py = hb.py(); p.out_pb = hb.pb(); p.out_off = hb.interior();
             p.act = 1; p.slope = 0.f;
             const bool f16x2 = gb_uses_f16x2(h, r, 2 * C, 128);
-            p.out_split = f16x2 ? 2 : (h->prec == PREC_BF16X3 ? 1 : 0);
+            p.out_split = gb8 ? 3 : f16x2 ? 2 : (h->prec == PREC_BF16X3 ? 1 : 0);
             em.flops = 2.0 * B * r * r * 18.0 * 128;
             em.on_aux = true;
             em.aux_group = i <= 4 ? 0 : 1;        // rb1-4 embeds are small and done early; rb5-6 carry the bytes
@@ -809,6 +869,14 @@ int plan_spade(msr_handle* h) {
             snprintf(k, sizeof k, "gen.rb%d.spade_%d.gb.bias", i, j); const float* gbb = need(k);
             Op gb = conv_op(hb, gbw, gbb, B, r, 2 * C, 1, EPI_SPADE, h->prec);
             if (f16x2) gb.conv.prec = PREC_F16X2;     // same tile, same layouts; fp16 encodings, 2 MFMAs per product
+            if (gb8) {
+                snprintf(k, sizeof k, "gen.rb%d.spade_%d.gb.kernel.wexp", i, j);
+                gb.conv.prec = PREC_FP8;
+                gb.conv.wexp = reinterpret_cast<const int*>(need(k));
+                gb.flops = 2.0 * B * r * r * 128.0 * (2 * C) * 9;           // algorithmic (the padded channels are zeros)
+                if (gb.tile != TILE_256x128_PP || gb.conv.ksplit != 1) return fail(h, MSR_ERR_STATE, "fp8 plan: rb%d gb%d is not a whole-tile ping-pong launch", i, j);
+            }
+            if (cv8) gb.conv.out_split = 3;           // its epilogue writes bf8 bytes for the fp8 consumer
             set_out_padded(gb.conv, ab);
             set_aux_dense(gb.conv, x, rx, C, xshift);
             gb.conv.mean = mean; gb.conv.stdv = stdv;
@@ -818,6 +886,13 @@ int plan_spade(msr_handle* h) {
             snprintf(k, sizeof k, "gen.rb%d.conv_%d.kernel", i, conv_idx); const float* cw = need(k);
             snprintf(k, sizeof k, "gen.rb%d.conv_%d.bias", i, conv_idx); const float* cb = need(k);
             Op cv = conv_op(ab, cw, cb, B, r, f, 1, epi, h->prec);
+            if (cv8) {
+                snprintf(k, sizeof k, "gen.rb%d.conv_%d.kernel.wexp", i, conv_idx);
+                cv.conv.prec = PREC_FP8;
+                cv.conv.wexp = reinterpret_cast<const int*>(need(k));
+                cv.flops = 2.0 * B * r * r * (double)C * f * 9;
+                if (cv.tile != TILE_256x128_PP || cv.conv.ksplit != 1) return fail(h, MSR_ERR_STATE, "fp8 plan: rb%d conv_%d is not a whole-tile ping-pong launch", i, conv_idx);
+            }
             set_out_dense(cv.conv, y, r, f);
             if (epi == EPI_RES) set_aux_dense(cv.conv, res, res_r, f, res_shift);
             // fused output moments (the tensor feeds a SPADE layer) unless the layer runs split-K
@@ -1315,6 +1390,43 @@ int msr_op_conv3x3_bf16x3(msr_handle* h, const float* in_dev, const float* wt_de
     if ((tile & 0x3F) == TILE_128x128_K16) return fail(h, MSR_ERR_INVALID, "the bf16x3 path has no 16-channel K-step tile");
     return op_conv_impl(h, in_dev, wt_dev, bias_dev, out_dev, B, rout, Cin, N, stride, epilogue, aux_dev, aux_shift,
                         mean_dev, std_dev, out_padded, tile, PREC_BF16X3, out_split, stream);
+}
+
+int64_t msr_quantize_e4m3(const float* host, int64_t n, uint8_t* out) {
+    if (!host || !out || n < 0) return -1;
+    for (int64_t i = 0; i < n; ++i) out[i] = msr_f32_to_e4m3(host[i]);
+    return n;
+}
+
+int msr_op_conv3x3_fp8(msr_handle* h, const void* in_dev, const void* wt_dev, const int32_t* wexp_dev, const float* bias_dev,
+                       float* out_dev, int32_t B, int32_t rout, int32_t Cpad, int32_t N, int32_t epilogue,
+                       const float* aux_dev, int32_t aux_shift, const float* mean_dev, const float* std_dev,
+                       int32_t out_padded, int32_t out_mode, void* stream) {
+    if (!h) return MSR_ERR_INVALID;
+    if (!in_dev || !wt_dev || !wexp_dev || !bias_dev || !out_dev || B < 1 || rout < 16 || Cpad % 256 || N % 128)
+        return fail(h, MSR_ERR_INVALID, "msr_op_conv3x3_fp8: bad argument (Cpad %% 256, N %% 128, rout >= 16)");
+    if (epilogue < EPI_BIAS || epilogue > EPI_SPADE || (epilogue != EPI_BIAS && !aux_dev) ||
+        (epilogue == EPI_SPADE && (!mean_dev || !std_dev)) || (out_mode != 0 && out_mode != 1 && out_mode != 3) ||
+        (out_mode != 0 && epilogue != EPI_SPADE))
+        return fail(h, MSR_ERR_INVALID, "msr_op_conv3x3_fp8: bad epilogue / output mode");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    Padded in; in.base = const_cast<float*>(static_cast<const float*>(in_dev)); in.r = rout; in.C = Cpad / 4;
+    Op op = conv_op(in, static_cast<const float*>(wt_dev), bias_dev, B, rout, N, 1, epilogue, PREC_BF16X3);
+    op.tile = TILE_256x128_PP;
+    op.conv.ksplit = 1;
+    op.conv.wt_frag = 0;
+    op.conv.prec = PREC_FP8;
+    op.conv.wexp = wexp_dev;
+    op.conv.out_split = epilogue == EPI_SPADE ? out_mode : 0;
+    const int Cout = epilogue == EPI_SPADE ? N / 2 : N;
+    const int oslots = out_mode == 3 ? fp8_pad(Cout) / 4 : Cout;
+    if (out_padded) { Padded o; o.base = out_dev; o.r = rout; o.C = oslots; set_out_padded(op.conv, o); }
+    else set_out_dense(op.conv, out_dev, rout, oslots);
+    if (epilogue != EPI_BIAS) set_aux_dense(op.conv, aux_dev, rout >> aux_shift, Cout, aux_shift);
+    op.conv.mean = mean_dev; op.conv.stdv = std_dev;
+    hipError_t e = launch_conv_igemm(op.conv, epilogue, op.tile, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(h, MSR_ERR_INVALID, "fp8 conv launch rejected: %s", hipGetErrorString(e));
+    return MSR_OK;
 }
 
 int msr_op_split_bf16(msr_handle* h, const float* in_dev, float* out_dev, int64_t count, void* stream) {

@@ -24,6 +24,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // Workgroup barrier of the ping-pong kernel, spelled as what it is on gfx950: a workgroup-scope release (every LDS
 // store of this wave has completed: s_waitcnt lgkmcnt(0)), the hardware s_barrier, a workgroup-scope acquire.  That is
@@ -302,7 +304,7 @@ __device__ __forceinline__ void halo16_epilogue_partial(const ConvParams& p, f32
             *reinterpret_cast<float4*>(pbase + (size_t)(y0 + i) * p.Wout * p.N + j * 16) = f4(acc[i][j]);
 }
 
-template <int EPI, bool SPLIT>
+template <int EPI, bool SPLIT, bool OUT8 = false>
 __device__ __forceinline__ void halo16_epilogue_body(const ConvParams& p, f32x4 (&acc)[4][4], int wm, int wn, int lane,
                                                      int n0, int tx0, int ty0, int b0, int stat_tile,
                                                      float4 (&xin)[4][2], float4 (&cv)[8]) {
@@ -334,7 +336,13 @@ __device__ __forceinline__ void halo16_epilogue_body(const ConvParams& p, f32x4 
                     const float t = (acc[i][jj][k] + gq[k]) * normalized + (acc[i][jj + 2][k] + bq[k]);
                     v[k] = t >= 0.f ? t : t * p.slope;
                 }
-                if constexpr (SPLIT) {
+                if constexpr (OUT8) {
+                    // bf8 e5m2 bytes for a PREC_FP8 consumer: 4 consecutive channels = one dword
+                    unsigned w8 = 0;
+                    w8 = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], w8, false);
+                    w8 = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], w8, true);
+                    reinterpret_cast<unsigned*>(orow)[(ch0 + jj * 16 + 4 * cg) >> 2] = w8;
+                } else if constexpr (SPLIT) {
                     // chunk image of the pixel: 16 words of hi pairs, 16 words of lo pairs
                     unsigned h01, l01, h23, l23;
                     msr_split_bf16_pk(v[0], v[1], h01, l01);
@@ -400,7 +408,8 @@ __device__ __forceinline__ void halo16_epilogue(const ConvParams& p, const TileG
                                                 float4 (&cv)[8]) {
     const int stat_tile = (b0 * g.tiles_y + (ty0 >> g.th_l)) * g.tiles_x + (tx0 >> g.tw_l);
     if constexpr (EPI == EPI_SPADE) {
-        if (p.out_split) halo16_epilogue_body<EPI, true>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile, xin, cv);
+        if (p.out_split == 3) halo16_epilogue_body<EPI, true, true>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile, xin, cv);
+        else if (p.out_split) halo16_epilogue_body<EPI, true>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile, xin, cv);
         else halo16_epilogue_body<EPI, false>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile, xin, cv);
     } else {
         halo16_epilogue_body<EPI, false>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile, xin, cv);
@@ -1097,9 +1106,13 @@ conv_igemm_bf16x3_halo(const ConvParams p, const TileGeom g) {
 // F16X2 = true is the opt-in 2-term form for the gamma|beta convs (kernels.h PREC_F16X2): operands are split-fp16
 // words, the weight's lo half is neither read from LDS nor multiplied: 32 MFMAs and 12 ds_read_b128 per K-step
 // instead of 48 and 16.
-template <int EPI, bool F16X2>
+// MODE 2 (PP_FP8) is the declared non-parity fp8 form (kernels.h PREC_FP8): a chunk row holds 128 one-byte channels,
+// a K-step is 128 channels of one tap: 16 block-scaled MFMAs (K = 128 each), same staging and fragment reads.
+enum PpMode : int { PP_BF16X3 = 0, PP_F16X2 = 1, PP_FP8 = 2 };
+template <int EPI, int MODE>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
+    constexpr bool F16X2 = MODE == PP_F16X2;
     constexpr int NTHR = 512, BN = 128, BKC = 32, BKP = 40;
     constexpr int TH = 16, TW = 16, HW = TW + 2, HP = (TH + 2) * HW;          // 324 halo pixels
     constexpr int H_ITEMS = (HP * 8 + NTHR - 1) / NTHR;                        // 6 16-byte items per thread
@@ -1176,6 +1189,7 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
         b_frag[i] = ((wn * 4 + i) * 16 + (lane & 15)) * BKP + 4 * (lane >> 4);
     }
     f32x4 acc[4][4];
+    int wsc[4] = {0x7F7F7F7F, 0x7F7F7F7F, 0x7F7F7F7F, 0x7F7F7F7F};   // PP_FP8: e8m0 weight scales of the wave's 4 x 16 rows
 
     const unsigned w_tap_bytes = (unsigned)((size_t)p.N * p.Cin * sizeof(float));
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
@@ -1188,6 +1202,7 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
     float4 rh0, rh1, rh2, rh3, rh4, rh5;          // halo of the next chunk in flight
     float4 rw0, rw1;                              // weights of the next K-step in flight
     bf16x8 ah[4], al[4], bh[4], bl[4];            // fragments of the current K-step
+    i32x8 qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3; // ... PP_FP8: the same 32 bytes per lane as ONE 8-register operand
     float4 xpre[4][2], cpre[8];                   // the epilogue's memory operands, requested on step 16 of the last pair
 #define MSR_BUFLD(rs, voff, soff) \
     __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (int)(soff), 0))
@@ -1243,17 +1258,37 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
         if ((T) % 9 == 7) MSR_WRITE_H_HI((((T) / 9) & 1) ^ 1);                                   \
         const float* a_ = Ah + (((T) / 9) & 1) * HP * BKP + ((((T) % 9) / 3) * HW + (((T) % 9) % 3)) * BKP; \
         const float* b_ = Bs + ((T) & 1) * BN * BKP;                                             \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
-            ah[i] = *reinterpret_cast<const bf16x8*>(a_ + a_frag[i]);                            \
-            al[i] = *reinterpret_cast<const bf16x8*>(a_ + a_frag[i] + 16);                       \
-            bh[i] = *reinterpret_cast<const bf16x8*>(b_ + b_frag[i]);                            \
-            if constexpr (!F16X2) bl[i] = *reinterpret_cast<const bf16x8*>(b_ + b_frag[i] + 16); \
+        if constexpr (MODE == PP_FP8) {                                                          \
+            /* the K = 128 MFMA takes 8 consecutive registers per operand: both 16-byte halves into one vector */ \
+            MSR_RD8(qa0, a_ + a_frag[0]) MSR_RD8(qa1, a_ + a_frag[1]) MSR_RD8(qa2, a_ + a_frag[2]) MSR_RD8(qa3, a_ + a_frag[3]) \
+            MSR_RD8(qb0, b_ + b_frag[0]) MSR_RD8(qb1, b_ + b_frag[1]) MSR_RD8(qb2, b_ + b_frag[2]) MSR_RD8(qb3, b_ + b_frag[3]) \
+        } else {                                                                                 \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                      \
+                ah[i] = *reinterpret_cast<const bf16x8*>(a_ + a_frag[i]);                        \
+                al[i] = *reinterpret_cast<const bf16x8*>(a_ + a_frag[i] + 16);                   \
+                bh[i] = *reinterpret_cast<const bf16x8*>(b_ + b_frag[i]);                        \
+                if constexpr (!F16X2) bl[i] = *reinterpret_cast<const bf16x8*>(b_ + b_frag[i] + 16); \
+            }                                                                                    \
         }                                                                                        \
     }
 // M(T): matrix segment, registers only (weights as the row operand: D[channel][pixel])
+#define MSR_RD8(dst, ptr)                                                                        \
+    {                                                                                            \
+        const i32x4 lo_ = *reinterpret_cast<const i32x4*>(ptr);                                  \
+        const i32x4 hi_ = *reinterpret_cast<const i32x4*>((ptr) + 16);                           \
+        dst = __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7);                         \
+    }
+#define MSR_MF8(J, WQ)                                                                           \
+    acc[0][J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(WQ, qa0, acc[0][J], 0, 1, 0, wsc[J], 0, 0x7F7F7F7F); \
+    acc[1][J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(WQ, qa1, acc[1][J], 0, 1, 0, wsc[J], 0, 0x7F7F7F7F); \
+    acc[2][J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(WQ, qa2, acc[2][J], 0, 1, 0, wsc[J], 0, 0x7F7F7F7F); \
+    acc[3][J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(WQ, qa3, acc[3][J], 0, 1, 0, wsc[J], 0, 0x7F7F7F7F);
 #define MSR_F16(v) __builtin_bit_cast(f16x8, v)
 #define MSR_M()                                                                                  \
-    if constexpr (F16X2) {                                                                       \
+    if constexpr (MODE == PP_FP8) {                                                              \
+        /* weights fp8 e4m3 (row operand, per-channel e8m0 scale in wsc[j]) x activations bf8 e5m2 (unit scale) */ \
+        MSR_MF8(0, qb0) MSR_MF8(1, qb1) MSR_MF8(2, qb2) MSR_MF8(3, qb3)                          \
+    } else if constexpr (F16X2) {                                                                \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                          \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                        \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(MSR_F16(bh[j]), MSR_F16(al[i]), acc[i][j], 0, 0, 0); \
@@ -1282,7 +1317,7 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
     {                                                                                            \
         MSR_STAMP()                                                                              \
         MSR_R(T, LASTP)                                                                          \
-        if ((LASTP) && (T) == 16 && EPI != EPI_PARTIAL) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0); \
+        if ((LASTP) && (T) == 16 && EPI != EPI_PARTIAL && MODE != PP_FP8) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0); \
         MSR_STAMP()                                                                              \
         MSR_WG_BARRIER()                                                                         \
         MSR_STAMP()                                                                              \
@@ -1327,6 +1362,10 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+        if constexpr (MODE == PP_FP8) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wsc[j] = p.wexp[n0 + wn * 64 + j * 16 + (lane & 15)];
+        }
         h_pair = 0;
         w_pair = 0;
         for (int pr = 0; pr < ppi - 1; ++pr) {
@@ -1343,6 +1382,9 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
         MSR_PAIR(true)
         // The epilogue of a tile shares a barrier interval with R(0) of the next one: X runs it beside Y's last M,
         // Y beside X's first M of the next tile.  Its stores are not waited for.
+        // PP_FP8: the scaled MFMA does not accumulate in place under register pressure, so its epilogue operands are
+        // not held across the last K-steps but requested here
+        if constexpr (MODE == PP_FP8) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0);
         if constexpr (EPI == EPI_PARTIAL) halo16_epilogue_partial(p, acc, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0, ks0);
         else halo16_epilogue<EPI>(p, ge, acc, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0, xpre, cpre);
         if (!has_next) break;
@@ -1374,6 +1416,8 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
 #undef MSR_R
 #undef MSR_M
 #undef MSR_F16
+#undef MSR_RD8
+#undef MSR_MF8
 #undef MSR_STEP
 #undef MSR_PAIR
 }
@@ -1506,8 +1550,9 @@ static hipError_t set_attr_halo() {
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_pp<EPI, F16>),               \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_LDS)) != hipSuccess)      \
         return e;
-    MSR_SETPP(EPI_BIAS, false) MSR_SETPP(EPI_RES, false) MSR_SETPP(EPI_SPADE, false) MSR_SETPP(EPI_SPADE, true)
-    MSR_SETPP(EPI_PARTIAL, false)
+    MSR_SETPP(EPI_BIAS, PP_BF16X3) MSR_SETPP(EPI_RES, PP_BF16X3) MSR_SETPP(EPI_SPADE, PP_BF16X3)
+    MSR_SETPP(EPI_SPADE, PP_F16X2) MSR_SETPP(EPI_PARTIAL, PP_BF16X3)
+    MSR_SETPP(EPI_BIAS, PP_FP8) MSR_SETPP(EPI_RES, PP_FP8) MSR_SETPP(EPI_SPADE, PP_FP8)
 #undef MSR_SETPP
 #define MSR_SET(EPI)                                                                                          \
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_halo<EPI, 0>),               \
@@ -1767,8 +1812,8 @@ static hipError_t launch_pp(const ConvParams& p, int epi, hipStream_t s) {
     const int grid = items < n_cu ? ((items + 7) & ~7) : n_cu;
     if (ksn > 1) {
         // few tiles: K ranges fill the chip, raw accumulators go to the split-K workspace, one more pass finishes
-        if (!p.partial || p.prec != PREC_BF16X3) return hipErrorInvalidValue;
-        conv_igemm_bf16x3_pp<EPI_PARTIAL, false><<<grid, 512, PP_LDS, s>>>(p, g);
+        if (!p.partial || p.prec != PREC_BF16X3) return hipErrorInvalidValue;     // K ranges exist in the 3-term form only
+        conv_igemm_bf16x3_pp<EPI_PARTIAL, PP_BF16X3><<<grid, 512, PP_LDS, s>>>(p, g);
         const int Cout = epi == EPI_SPADE ? p.N / 2 : p.N;
         long eb = ((long)p.B * p.Hout * p.Wout * (Cout / 4) + 255) / 256;
         if (eb > 4096) eb = 4096;
@@ -1780,20 +1825,31 @@ static hipError_t launch_pp(const ConvParams& p, int epi, hipStream_t s) {
     }
     if (p.prec == PREC_F16X2) {
         if (epi != EPI_SPADE) return hipErrorInvalidValue;     // the 2-term form exists for the gamma|beta convs only
-        conv_igemm_bf16x3_pp<EPI_SPADE, true><<<grid, 512, PP_LDS, s>>>(p, g);
+        conv_igemm_bf16x3_pp<EPI_SPADE, PP_F16X2><<<grid, 512, PP_LDS, s>>>(p, g);
+        return hipGetLastError();
+    }
+    if (p.prec == PREC_FP8) {
+        if (!p.wexp) return hipErrorInvalidValue;
+        switch (epi) {
+            case EPI_BIAS: conv_igemm_bf16x3_pp<EPI_BIAS, PP_FP8><<<grid, 512, PP_LDS, s>>>(p, g); break;
+            case EPI_RES: conv_igemm_bf16x3_pp<EPI_RES, PP_FP8><<<grid, 512, PP_LDS, s>>>(p, g); break;
+            case EPI_SPADE: conv_igemm_bf16x3_pp<EPI_SPADE, PP_FP8><<<grid, 512, PP_LDS, s>>>(p, g); break;
+            default: return hipErrorInvalidValue;
+        }
         return hipGetLastError();
     }
     switch (epi) {
-        case EPI_BIAS: conv_igemm_bf16x3_pp<EPI_BIAS, false><<<grid, 512, PP_LDS, s>>>(p, g); break;
-        case EPI_RES: conv_igemm_bf16x3_pp<EPI_RES, false><<<grid, 512, PP_LDS, s>>>(p, g); break;
-        case EPI_SPADE: conv_igemm_bf16x3_pp<EPI_SPADE, false><<<grid, 512, PP_LDS, s>>>(p, g); break;
+        case EPI_BIAS: conv_igemm_bf16x3_pp<EPI_BIAS, PP_BF16X3><<<grid, 512, PP_LDS, s>>>(p, g); break;
+        case EPI_RES: conv_igemm_bf16x3_pp<EPI_RES, PP_BF16X3><<<grid, 512, PP_LDS, s>>>(p, g); break;
+        case EPI_SPADE: conv_igemm_bf16x3_pp<EPI_SPADE, PP_BF16X3><<<grid, 512, PP_LDS, s>>>(p, g); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
 hipError_t launch_conv_igemm(const ConvParams& p, int epilogue, int tile, hipStream_t s) {
-    if (p.prec == PREC_F16X2) return tile == TILE_256x128_PP ? launch_pp(p, epilogue, s) : hipErrorInvalidValue;
+    if (p.prec == PREC_F16X2 || p.prec == PREC_FP8)
+        return tile == TILE_256x128_PP ? launch_pp(p, epilogue, s) : hipErrorInvalidValue;
     if (p.prec == PREC_BF16X3) {
         if (tile == TILE_256x128_PP) return launch_pp(p, epilogue, s);
         if (tile == TILE_128x128_HALO) return launch_halo(p, epilogue, 0, s);

@@ -46,9 +46,13 @@ struct ConvParams {
     int ksplit;                   // > 1: the K loop is cut into ksplit ranges, one workgroup each (low-res layers)
     float* partial;               // [ksplit][B*Hout*Wout][N] workspace for split-K
     int prec;                     // PREC_F32: operands are fp32; PREC_BF16X3: operands are split-bf16 words
-    int out_split;                // EPI_SPADE only: write the split-bf16 image (the consumer conv runs PREC_BF16X3)
+    int out_split;                // EPI_SPADE only: 1 = write the split-bf16 image (the consumer conv runs PREC_BF16X3 / its
+                                  // fp16 twin decided by the producer of the mask embedding), 3 = write bf8 e5m2 bytes
+                                  // (PREC_FP8 consumer: one byte per channel, dword index = channel / 4)
     float* stat_partial;          // EPI_BIAS / EPI_RES, ksplit == 1: per-wave partial moments of the OUTPUT,
                                   // [P][3][N] = (count, mean, M2) per 32- or 64-row slab (P = conv_stat_slabs)
+    const int* wexp;              // PREC_FP8: [N] e8m0 exponent of every output channel's weight scale, replicated in the
+                                  // four bytes of the word (the MFMA's scale operand)
     int wt_frag;                  // PREC_BF16X3: weights are in MFMA-fragment order (conv_igemm_bf16x3, B in VGPRs)
                                   // instead of the split-bf16 image of [tap][N][Cin] (LDS-staged B)
 };
@@ -62,7 +66,12 @@ struct ConvParams {
 // halves (hi = f16_rn(v), lo = f16_rn(v - hi), ~22 bits) and the weight is ONE fp16 (11 bits, the lo half of its
 // chunk image is stored but not read): a * w ~= a_hi*w_hi + a_lo*w_hi on v_mfma_f32_16x16x32_f16, two MFMAs instead
 // of three, per-product error <= 2^-12 (the weight's rounding).  Same tensor layout as split-bf16, fp16 encodings.
-enum ConvPrecision : int { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_F16X2 = 2 };
+// PREC_FP8 (declared NON-parity mode, BASELINE configs[4]): weights quantised to fp8 e4m3 with a power-of-two scale per
+// output channel, activations to bf8 e5m2 (no scale: its range covers the activations), one product per element on the
+// block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 (128 channels of one tap per instruction, twice the bf16 rate); the
+// per-channel weight scale rides in the instruction's e8m0 scale operand, fp32 accumulation.  Tensors hold one byte per
+// channel; the kernel sees them as float slots of 4 channels (Cin / 4 "channels", same indexing as the other modes).
+enum ConvPrecision : int { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_F16X2 = 2, PREC_FP8 = 3 };
 
 __host__ __device__ inline unsigned msr_bf16_rn(float v) {   // round-to-nearest-even, finite inputs
     union { float f; unsigned u; } c;
@@ -120,6 +129,26 @@ __host__ __device__ inline void msr_store_split4_f16(float* pixel, int c, float 
     chunk[16] = l0 | (l1 << 16); chunk[17] = l2 | (l3 << 16);
 }
 
+// fp32 -> fp8 e4m3 (OCP "fn": bias 7, max 448, no infinity), round to nearest even, saturating; host side of the
+// PREC_FP8 weight upload (the device side converts with v_cvt_pk_bf8_f32 / v_cvt_pk_fp8_f32)
+inline unsigned char msr_f32_to_e4m3(float v) {
+    const unsigned char sign = v < 0.f ? 0x80 : 0;
+    float a = v < 0.f ? -v : v;
+    if (!(a == a)) return 0x7F;
+    if (a >= 448.f) return sign | 0x7E;
+    if (a < 0.0009765625f) return sign;                      // below half the smallest subnormal (2^-9 / 2): zero
+    int e;
+    (void)__builtin_frexpf(a, &e);                           // a = m * 2^e, m in [0.5, 1)
+    e -= 1;                                                  // a = 1.m * 2^e
+    if (e < -6) e = -6;                                      // subnormal range shares the exponent of 2^-6
+    const float q = __builtin_ldexpf(1.f, e - 3);            // spacing of representable values in this binade
+    float r = __builtin_nearbyintf(a / q);                   // RNE in the default rounding mode
+    if (r >= 16.f) { r = 8.f; e += 1; }                      // carried into the next binade
+    if (e > 8 || (e == 8 && r > 14.f)) return sign | 0x7E;
+    if (r < 8.f) return sign | (unsigned char)r;             // subnormal: exponent field 0, mantissa r
+    return sign | (unsigned char)(((e + 7) << 3) | ((int)r - 8));
+}
+
 enum ConvTile : int { TILE_128x128 = 0, TILE_64x64 = 1, TILE_128x128_K16 = 2, TILE_128x128_HALO = 3, TILE_128x128_HALO16 = 4, TILE_256x128_PP = 5 };
 
 hipError_t conv_igemm_init();   // sets dynamic-LDS attributes once
@@ -150,7 +179,8 @@ struct SmallCinParams {
     int out_px, out_py, out_pb, out_off;
     int act;            // 0 none, 1 relu, 2 leaky(slope)
     float slope;
-    int out_split;      // 1: write split-bf16 words for a PREC_BF16X3 consumer; 2: split-fp16 words (PREC_F16X2)
+    int out_split;      // 1: write split-bf16 words for a PREC_BF16X3 consumer; 2: split-fp16 words (PREC_F16X2);
+                        // 3: bf8 e5m2 bytes (PREC_FP8; one dword per 4 channels)
 };
 hipError_t launch_conv_smallcin(const SmallCinParams& p, hipStream_t s);
 hipError_t launch_split_bf16(const float* in, float* out, long n, hipStream_t s);

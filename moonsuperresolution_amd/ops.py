@@ -125,3 +125,55 @@ def conv3x3(ctx: OpContext, x_padded: torch.Tensor, w_kl: torch.Tensor, bias: to
                                     1 if out_padded else 0, tile, stream)
     _lib.raise_for(ctx.lib, ctx.h, rc, "msr_op_conv3x3")
     return out
+
+
+def fp8_weight_image(w_kl: torch.Tensor):
+    """Kernel-layout weights [taps][N][Cin] (fp32) -> (e4m3 bytes [taps][N][Cpad] uint8, wexp [N] int32, dequantised
+    fp32 weights) exactly as msr_load_weight quantises them for the fp8 mode: a power-of-two scale per output channel
+    that puts the channel's largest |w| into e4m3's top binade."""
+    taps, N, Cin = w_kl.shape
+    cpad = max(256, (Cin + 255) // 256 * 256)
+    amax = w_kl.abs().amax(dim=(0, 2)).double().cpu()
+    e = torch.zeros(N, dtype=torch.int64)
+    nz = amax > 0
+    e[nz] = torch.frexp((amax[nz] / 448.0).float())[1].to(torch.int64)
+    scale = torch.pow(2.0, e.double()).float().to(w_kl.device)
+    q = (w_kl / scale[None, :, None]).to(torch.float8_e4m3fn)
+    img = torch.zeros((taps, N, cpad), dtype=torch.uint8, device=w_kl.device)
+    img[:, :, :Cin] = q.view(torch.uint8)
+    b = (127 + e).to(torch.int64)
+    wexp = (b | (b << 8) | (b << 16) | (b << 24)).to(torch.int32).to(w_kl.device)
+    return img.contiguous(), wexp.contiguous(), q.float() * scale[None, :, None]
+
+
+def bf8_activation_image(x_padded: torch.Tensor):
+    """[B, r+2, r+2, C] fp32 -> (bf8 e5m2 bytes [B, r+2, r+2, Cpad] uint8, dequantised fp32 values)."""
+    C_ = x_padded.shape[-1]
+    cpad = max(256, (C_ + 255) // 256 * 256)
+    q = x_padded.to(torch.float8_e5m2)
+    img = torch.zeros(x_padded.shape[:-1] + (cpad,), dtype=torch.uint8, device=x_padded.device)
+    img[..., :C_] = q.view(torch.uint8)
+    return img.contiguous(), q.float()
+
+
+def conv3x3_fp8(ctx: OpContext, x_bytes: torch.Tensor, w_bytes: torch.Tensor, wexp: torch.Tensor, bias: torch.Tensor,
+                rout: int, epilogue: int = EPI_BIAS, aux: Optional[torch.Tensor] = None, aux_shift: int = 0,
+                mean: Optional[torch.Tensor] = None, std: Optional[torch.Tensor] = None, out_padded: bool = False,
+                out_mode: int = 0) -> torch.Tensor:
+    """One launch of the fp8 form of the persistent ping-pong conv (msr_op_conv3x3_fp8)."""
+    B, cpad = x_bytes.shape[0], x_bytes.shape[3]
+    N = w_bytes.shape[1]
+    Cout = N // 2 if epilogue == EPI_SPADE else N
+    if out_mode == 3:
+        opad = max(256, (Cout + 255) // 256 * 256)
+        shape = (B, rout + 2, rout + 2, opad) if out_padded else (B, rout, rout, opad)
+        out = torch.zeros(shape, dtype=torch.uint8, device=x_bytes.device)
+    else:
+        shape = (B, rout + 2, rout + 2, Cout) if out_padded else (B, rout, rout, Cout)
+        out = torch.zeros(shape, dtype=torch.float32, device=x_bytes.device)
+    p = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+    rc = ctx.lib.msr_op_conv3x3_fp8(ctx.h, x_bytes.data_ptr(), w_bytes.data_ptr(), wexp.data_ptr(), bias.data_ptr(),
+                                    out.data_ptr(), B, rout, cpad, N, epilogue, p(aux), aux_shift, p(mean), p(std),
+                                    1 if out_padded else 0, out_mode, torch.cuda.current_stream(x_bytes.device).cuda_stream)
+    _lib.raise_for(ctx.lib, ctx.h, rc, "msr_op_conv3x3_fp8")
+    return out

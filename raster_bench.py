@@ -66,6 +66,9 @@ def main():
     ap.add_argument("--simulate-world", type=int, default=0, help="... of this many ranks (no process group)")
     ap.add_argument("--no-reference", dest="reference", action="store_false",
                     help="skip the generator-only pass (same calls, same streams, no tiler / stitcher) after the map")
+    ap.add_argument("--halo", action="store_true",
+                    help="patch-row-sharded mode (halo.py): every patch position generated once, neighbour exchange of "
+                         "the boundary-zone accumulators over send / recv; NOT reference-identical (see halo.py)")
     ap.add_argument("--passes", type=int, default=1, help="run the shard this many times; the last pass is reported")
     ap.add_argument("--precision", default="bf16x3")
     ap.add_argument("--pipeline", type=int, default=2)
@@ -108,6 +111,60 @@ def main():
     if args.simulate_world > 0:
         shard_rank, shard_world = args.simulate_rank, args.simulate_world
     mine = shard_tile_rows(tiles, shard_rank, shard_world)
+    if args.halo:
+        from moonsuperresolution_amd import HaloShardedSuperResolution
+        from moonsuperresolution_amd.distributed import all_gather_var_rows, halo_zone_rows
+        hs = HaloShardedSuperResolution(DSRConfig(image_size=S, stride=s, batch_size=B, tile_size=T), model=gen,
+                                        device=local, pipeline=args.pipeline)
+        hs.dem_shape, hs.img_shape = dsr.dem_shape, dsr.img_shape
+        hs.dem_padded, hs.img_padded = dsr.dem_padded, dsr.img_padded
+        hs.dem_padded_shape, hs.img_padded_shape = dsr.dem_padded_shape, dsr.img_padded_shape
+        gen.forward_device(torch.zeros((B, S, S, 2), device="cuda").uniform_(-0.5, 0.5))
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        st = hs.haloAccumulate(shard_rank, shard_world)
+        torch.cuda.synchronize()
+        t_acc = time.perf_counter() - t0
+        from_down = from_up = None
+        if world > 1:
+            from moonsuperresolution_amd.distributed import exchange_halo
+            from_down, from_up = exchange_halo(st["send_down"], st["send_up"], (3, st["down_rows"], st["wp"]),
+                                               (3, st["up_rows"], st["wp"]), rank, world)
+            torch.cuda.synchronize()
+        t_ex = time.perf_counter() - t0 - t_acc
+        (m, sd, g), (own_lo, own_hi) = hs.haloFinish(st, from_down, from_up)
+        torch.cuda.synchronize()
+        if world > 1 and args.gather:
+            ys, _ = hs.patchGrid()
+            zones = halo_zone_rows(ys, S, world)
+            counts = [(hs.dem_padded_shape[0] if z["own_hi"] is None else z["own_hi"]) - z["own_lo"] for z in zones]
+            m, sd, g = (all_gather_var_rows(t, counts) for t in (m, sd, g))
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        nv, nc = hs.last_counts_halo
+        tot = torch.tensor([nv, nc], dtype=torch.float64, device="cuda")
+        mx = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "raster end-to-end, halo mode (every patch position generated once; not reference-identical)",
+                "n_gpus": world, "raster": [args.rows, args.cols], "image_size": S, "stride": s, "batch_size": B,
+                "shard": [shard_rank, shard_world], "patches": int(tot[0]), "generator_calls": int(tot[1]),
+                "seconds": float(mx[0]), "seconds_accumulate_rank0": t_acc, "seconds_exchange_rank0": t_ex,
+                "patches_per_s": float(tot[0]) / float(mx[0]),
+                "tiles512_per_s": float(tot[1]) * B * (S / 512.0) ** 2 / float(mx[0]),
+                "own_rows_rank0": [own_lo, own_hi], "zone_bytes_sent_rank0":
+                    sum(int(t.numel()) * 4 for t in (st["send_down"], st["send_up"]) if t is not None),
+                "canvas": list(hs.dem_padded_shape), "precision": args.precision, "pipeline": args.pipeline}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     todo = mine[:args.max_tiles] if args.max_tiles else mine
     dev = torch.device("cuda", local)
     rows_all = tile_rows(tiles)

@@ -142,3 +142,29 @@ def test_clone_and_pipeline_follow_loaded_weights(hip_lib):
     m1, s1, g1 = d1.processMap(img, dem)
     assert np.array_equal(m1, m2) and np.array_equal(s1, s2) and np.array_equal(g1, g2)
     d1.close(); d2.close(); gen.close()
+
+
+FP8_TOL = 0.5      # declared, NON-parity: see the docstring below; tightened to the measured value once it is on record
+
+
+@pytest.mark.parametrize("S,B", [(256, 16), (512, 8)])
+def test_fp8_mode_declared_tolerance(hip_lib, S, B):
+    """BASELINE configs[4] ("fp16 with fp8 MFMA conv"): precision="fp8" runs the chip-filling gamma|beta and ResidualBlock
+    convs on fp8 e4m3 weights x bf8 e5m2 activations (3 and 2 mantissa bits).  It is NOT a parity mode: its relative
+    L-infinity against the oracle is measured here, printed, appended to gpurun_out/parity_baseline_configs.jsonl and
+    bounded by FP8_TOL — the tolerance this mode declares instead of north_star's 1e-3.  The kernels themselves are
+    exact on quantised operands (tests/test_gpu_conv_kernel.py::test_conv_fp8_exact_on_quantised_operands)."""
+    from moonsuperresolution_amd import Generator
+    x, w, eps, ref, cap, oracle_dtype = _oracle(S, B)
+    gen = Generator(S, B, variant="gaugan", weights=w, eps=eps, precision="fp8")
+    y = gen(x, training=False)
+    err = rel_linf(y, ref)
+    rms = float(np.sqrt(np.mean((np.asarray(y, np.float64) - ref) ** 2)) / np.sqrt(np.mean(ref ** 2)))
+    sw = S // 64
+    e_rb4 = rel_linf(gen.debug_tensor("ws.gen.rb4.out", (B, sw * 8, sw * 8, 512)), cap["gen.rb4.out"])
+    _record(S=S, B=B, precision="fp8", oracle=oracle_dtype, rel_linf_output=err, rel_rms_output=rms, rel_linf_rb4_out=e_rb4,
+            note="declared non-parity mode")
+    gen.close()
+    del gen
+    torch.cuda.empty_cache()
+    assert np.isfinite(y).all() and err <= FP8_TOL, err

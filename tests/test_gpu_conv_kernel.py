@@ -225,3 +225,68 @@ def test_conv_spade_epilogue_f16x2(ctx, B, r, C, shift):
     print("f16x2 kernel: rel Linf vs fp64", e_full, " vs fp64 with fp16-rounded weights", e_rounded)
     assert e_full <= 5e-4, e_full
     assert e_rounded <= 5e-5, e_rounded
+
+
+@pytest.mark.parametrize("B,r,cin,cout", [(2, 16, 256, 128), (1, 32, 512, 256), (3, 16, 128, 128), (20, 64, 256, 128)])
+def test_conv_fp8_exact_on_quantised_operands(ctx, B, r, cin, cout):
+    """The fp8 form of the ping-pong conv (declared non-parity mode): fp8 e4m3 weights with a power-of-two scale per
+    output channel in the MFMA's e8m0 scale operand, bf8 e5m2 activations, K = 128 per instruction, fp32 accumulation.
+    Operands are quantised HERE with torch's float8 types; against a float64 conv of the de-quantised operands the
+    kernel must be exact up to fp32 accumulation (<= 1e-5): that pins the byte layout, the operand pairing of the
+    128-deep MFMA, the channel padding (cin = 128 -> 256) and the scale plumbing.  The quantisation error itself is what
+    the mode declares (tests/test_gpu_baseline_configs.py)."""
+    from moonsuperresolution_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(41 + B + r)
+    x = torch.randn((B, r, r, cin), generator=g).cuda()
+    w = (torch.randn((3, 3, cin, cout), generator=g) / np.sqrt(9 * cin) * torch.logspace(-2, 1, cout)).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    xb, xdq = ops.bf8_activation_image(ops.pad_nhwc(x))
+    wb, wexp, wdq = ops.fp8_weight_image(ops.kernel_layout(w))
+    y = ops.conv3x3_fp8(ctx, xb, wb, wexp, b, r)
+    w_hwio = wdq.permute(0, 2, 1).reshape(3, 3, cin, cout)
+    ref = ref_conv(xdq[:, 1:-1, 1:-1], w_hwio, b, 1)
+    assert rel_linf(y.cpu().numpy(), ref.numpy()) <= 1e-5
+    # and the declared error of the quantisation itself, for the record
+    print("fp8 conv vs unquantised fp64 conv: rel Linf", rel_linf(y.cpu().numpy(), ref_conv(x, w, b, 1).numpy()))
+
+
+def test_conv_fp8_spade_epilogue_bf8_output(ctx):
+    """SPADE epilogue of the fp8 gamma|beta conv writing bf8 bytes (padded to 256 channels) for an fp8 consumer, and
+    split-bf16 words for a bf16x3 consumer."""
+    from moonsuperresolution_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(43)
+    B, r, C, shift = 3, 32, 128, 1
+    h = torch.relu(torch.randn((B, r, r, 128), generator=g)).cuda()
+    wg = (torch.randn((3, 3, 128, C), generator=g) / 34).cuda()
+    wb_ = (torch.randn((3, 3, 128, C), generator=g) / 34).cuda()
+    bg, bb = torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+    x = (3 + 2 * torch.randn((B, r >> shift, r >> shift, C), generator=g)).cuda()
+    mean = x.mean((0, 1, 2)).contiguous()
+    std = torch.sqrt(x.var((0, 1, 2), unbiased=False) + 1e-5).contiguous()
+    w, bias = ops.spade_layout(wg, wb_, bg, bb)
+    hb, hdq = ops.bf8_activation_image(ops.pad_nhwc(h))
+    wq, wexp, wdq = ops.fp8_weight_image(w)
+    # reference on the de-quantised operands: un-interleave the (32 gamma | 32 beta) rows
+    c = torch.arange(C)
+    rows_g = ((c // 32) * 64 + (c % 32)).cuda()
+    wdq_hwio = wdq.permute(0, 2, 1).reshape(3, 3, 128, 2 * C)
+    xr = x.double().cpu().repeat_interleave(2, 1).repeat_interleave(2, 2)
+    xn = (xr - mean.double().cpu()) / std.double().cpu()
+    v = ref_conv(hdq[:, 1:-1, 1:-1], wdq_hwio[..., rows_g], bg, 1) * xn + ref_conv(hdq[:, 1:-1, 1:-1], wdq_hwio[..., rows_g + 32], bb, 1)
+    v = torch.where(v >= 0, v, 0.2 * v)
+    y32 = ops.conv3x3_fp8(ctx, hb, wq, wexp, bias, r, epilogue=ops.EPI_SPADE, aux=x, aux_shift=shift, mean=mean, std=std,
+                          out_padded=True, out_mode=0)
+    assert rel_linf(y32.cpu()[:, 1:-1, 1:-1].numpy(), v.numpy()) <= 1e-5
+    ys = ops.conv3x3_fp8(ctx, hb, wq, wexp, bias, r, epilogue=ops.EPI_SPADE, aux=x, aux_shift=shift, mean=mean, std=std,
+                         out_padded=True, out_mode=1)
+    hi, lo = unsplit(ys)
+    assert rel_linf((hi + lo).cpu()[:, 1:-1, 1:-1].numpy(), v.numpy()) <= 5e-5
+    y8 = ops.conv3x3_fp8(ctx, hb, wq, wexp, bias, r, epilogue=ops.EPI_SPADE, aux=x, aux_shift=shift, mean=mean, std=std,
+                         out_padded=True, out_mode=3)
+    assert y8.shape == (B, r + 2, r + 2, 256)
+    got = y8[..., :C].view(torch.float8_e5m2).float().cpu()[:, 1:-1, 1:-1]
+    want = v.float().to(torch.float8_e5m2).float()
+    mism = (got != want)
+    assert float(mism.float().mean()) <= 2e-3                    # values on a rounding boundary may fall either way
+    assert float(((got - want).abs() / want.abs().clamp_min(1e-6))[mism].max() if mism.any() else 0.0) <= 0.26   # one bf8 ulp
+    assert int(y8[..., C:].max()) == 0 and int(y8[:, 0].max()) == 0      # channel padding and border stay zero

@@ -92,3 +92,23 @@ def test_tile_row_sharding():
     assert sizes == [2, 2, 2, 2, 2, 2, 2, 1] and sorted(seen) == sorted(tiles)
     assert shard_tile_rows(tiles, 0, 1) == tiles
     assert shard_tile_rows(tiles[:69], 1, 2) == []      # fewer rows than ranks: some ranks idle
+
+
+def test_e4m3_quantiser_matches_torch():
+    """msr_quantize_e4m3 (what msr_load_weight applies in the fp8 mode) against torch.float8_e4m3fn on a sweep that
+    covers every binade, the subnormals, the rounding ties, the saturation at 448 and both signs."""
+    import ctypes as C
+    import torch
+    from moonsuperresolution_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    vals = np.concatenate([
+        rng.standard_normal(20000) * np.exp(rng.uniform(-12, 7, 20000)),
+        np.array([0.0, -0.0, 448.0, 449.0, 1e9, -1e9, 2.0 ** -9, 2.0 ** -10, 3 * 2.0 ** -10, 2.0 ** -6, 464.0, 479.9, 17.0, 18.0, 19.0]),
+        (np.arange(0, 256) + 0.5) * 2.0 ** -9, np.arange(1, 32) * 0.0625 + 0.03125]).astype(np.float32)
+    out = np.empty(vals.size, np.uint8)
+    assert lib.msr_quantize_e4m3(vals.ctypes.data_as(C.c_void_p), vals.size, out.ctypes.data_as(C.c_void_p)) == vals.size
+    ref = torch.from_numpy(np.clip(vals, -448, 448)).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    got_f = torch.from_numpy(out).view(torch.float8_e4m3fn).float().numpy()
+    ref_f = torch.from_numpy(ref).view(torch.float8_e4m3fn).float().numpy()
+    assert np.array_equal(got_f, ref_f)              # compare values: +0 and -0 are the same weight
