@@ -590,9 +590,7 @@ int msr_load_weight(msr_handle* h, const char* name_c, const float* host, const 
         const bool is_beta = ends_with(name, ".conv_beta.kernel");
         const int cin = (int)s[2], C = (int)s[3];
         const std::string base = name.substr(0, name.rfind(".conv_"));
-        float* d = nullptr;
-        rc = dev_alloc(h, base + ".gb.kernel", (size_t)9 * 2 * C * cin, false, &d);
-        if (!rc) {
+        {
             std::vector<int> rowmap(C);
             for (int c = 0; c < C; ++c) rowmap[c] = (c / 32) * 64 + (is_beta ? 32 : 0) + (c % 32);
             // stage through a host image of the combined tensor; the other half is filled by the sibling call

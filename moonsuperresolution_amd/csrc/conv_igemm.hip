@@ -1288,6 +1288,10 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
     if constexpr (MODE == PP_FP8) {                                                              \
         /* weights fp8 e4m3 (row operand, per-channel e8m0 scale in wsc[j]) x activations bf8 e5m2 (unit scale) */ \
         MSR_MF8(0, qb0) MSR_MF8(1, qb1) MSR_MF8(2, qb2) MSR_MF8(3, qb3)                          \
+        /* pin the accumulators here: without a use in this segment LLVM sinks the whole MFMA chain of the last chunk  \
+           pair into the epilogue (per output row) and keeps 18 steps of fragments alive in scratch */ \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));     \
     } else if constexpr (F16X2) {                                                                \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                          \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                        \

@@ -144,7 +144,7 @@ def test_clone_and_pipeline_follow_loaded_weights(hip_lib):
     d1.close(); d2.close(); gen.close()
 
 
-FP8_TOL = 0.5      # declared, NON-parity: see the docstring below; tightened to the measured value once it is on record
+FP8_TOL = 0.25     # declared, NON-parity (measured 0.16 relative L-inf, 0.13 relative rms at both BASELINE sizes)
 
 
 @pytest.mark.parametrize("S,B", [(256, 16), (512, 8)])
