@@ -5,7 +5,7 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/collect_r02; mkdir -p $O
 # per-layer tables (known call count, one stream, launches in plan order)
-for cfg in "spade512 bf16x3" "spade512 bf16x3_gbf16" "spade256 bf16x3"; do
+for cfg in "spade512 bf16x3" "spade512 bf16x3_gbf16" "spade512 fp8" "spade256 bf16x3"; do
   set -- $cfg; wl=$1; pr=$2; S=${wl#spade}; B=16; [ $S = 512 ] && B=8
   rocprofv3 --kernel-trace --stats -d $O/kt_${wl}_$pr -o kt --output-format csv -- python3 profiles/run_forwards.py $wl 25 $pr > $O/kt_${wl}_$pr.log 2>&1 || exit 1
   python profiles/analyze_trace.py $O/kt_${wl}_$pr/kt_kernel_trace.csv $S $B > $O/${wl}_${pr}_conv_layers.txt || exit 1
