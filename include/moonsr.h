@@ -251,10 +251,10 @@ int msr_op_conv3x3_bf16x3(msr_handle* h, const float* in_dev, const float* wt_de
  * applies to the weights of the fp8 mode, exposed so that it can be checked against an independent implementation. */
 int64_t msr_quantize_e4m3(const float* host, int64_t n, uint8_t* out);
 /* Kernel-level entry of the fp8 form (MSR_FLAG_FP8) of the persistent ping-pong conv.
- *   in_dev   zero-bordered NHWC bf8 (e5m2) bytes [B, rout+2, rout+2, Cpad], Cpad % 256 == 0 (channels beyond the real
+ *   in_dev   zero-bordered NHWC bf8 (e5m2) bytes [B, rout+2, rout+2, Cpad], Cpad = 128 or a multiple of 256 (channels beyond the real
  *            ones are zero);  wt_dev  fp8 (e4m3) bytes [9][N][Cpad];  wexp_dev [N] int32: the e8m0 exponent (127 + e,
  *            weight = byte value * 2^e) of every output channel, replicated in the word's four bytes
- *   out_mode (SPADE epilogue) 0 = fp32 [.., N/2], 1 = split-bf16 words, 3 = bf8 bytes padded to a multiple of 256 channels
+ *   out_mode (SPADE epilogue) 0 = fp32 [.., N/2], 1 = split-bf16 words, 3 = bf8 bytes, 128 channels or padded to a multiple of 256
  *   epilogue / aux / mean / std as msr_op_conv3x3. */
 int msr_op_conv3x3_fp8(msr_handle* h, const void* in_dev, const void* wt_dev, const int32_t* wexp_dev,
                        const float* bias_dev, float* out_dev, int32_t B, int32_t rout, int32_t Cpad, int32_t N,

@@ -293,12 +293,13 @@ struct ConvVariant { int tile; int wt_frag; int ksplit; };   // ksplit 0: conv_p
 ConvVariant pick_conv_variant(int B, int rout, int N, int stride, int epi, int prec, int cin);
 
 // MSR_FLAG_FP8: a 3x3 stride-1 conv runs the fp8 form of the persistent ping-pong kernel when it fills the chip with
-// whole tiles (B * (r/16)^2 * (N/128) >= 256, no K split); its input then holds one byte per channel, padded to a
-// multiple of 256 channels (two 128-byte chunks: the kernel's unrolled chunk pair).
+// whole tiles (B * (r/16)^2 * (N/128) >= 256, no K split); its input then holds one byte per channel: 128 channels (one
+// 128-byte chunk) or a multiple of 256 (chunk pairs).
 bool conv_fills_pp(int B, int rout, int N) {
     return rout >= 16 && N % 128 == 0 && (long)B * (rout / 16) * (rout / 16) * (N / 128) >= 256;
 }
-int fp8_pad(int cin) { return cin < 256 ? 256 : (cin + 255) / 256 * 256; }
+// channels of an fp8 tensor: 128 (one chunk: the two-tiles-per-body form of the kernel) or a multiple of 256 (chunk pairs)
+int fp8_pad(int cin) { return cin <= 128 ? 128 : (cin + 255) / 256 * 256; }
 // gamma|beta conv of a SPADE layer normalising C channels at resolution r
 bool gb_uses_fp8(msr_handle* h, int rout, int C) { return h->fp8 && conv_fills_pp(h->B, rout, 2 * C); }
 // main conv cin -> cout fed by that SPADE layer (its producer must be a whole-tile ping-pong launch too: its epilogue
@@ -1401,8 +1402,9 @@ int msr_op_conv3x3_fp8(msr_handle* h, const void* in_dev, const void* wt_dev, co
                        const float* aux_dev, int32_t aux_shift, const float* mean_dev, const float* std_dev,
                        int32_t out_padded, int32_t out_mode, void* stream) {
     if (!h) return MSR_ERR_INVALID;
-    if (!in_dev || !wt_dev || !wexp_dev || !bias_dev || !out_dev || B < 1 || rout < 16 || Cpad % 256 || N % 128)
-        return fail(h, MSR_ERR_INVALID, "msr_op_conv3x3_fp8: bad argument (Cpad %% 256, N %% 128, rout >= 16)");
+    if (!in_dev || !wt_dev || !wexp_dev || !bias_dev || !out_dev || B < 1 || rout < 16 || (Cpad != 128 && Cpad % 256) ||
+        N % 128)
+        return fail(h, MSR_ERR_INVALID, "msr_op_conv3x3_fp8: bad argument (Cpad 128 or a multiple of 256, N %% 128, rout >= 16)");
     if (epilogue < EPI_BIAS || epilogue > EPI_SPADE || (epilogue != EPI_BIAS && !aux_dev) ||
         (epilogue == EPI_SPADE && (!mean_dev || !std_dev)) || (out_mode != 0 && out_mode != 1 && out_mode != 3) ||
         (out_mode != 0 && epilogue != EPI_SPADE))

@@ -1109,7 +1109,12 @@ conv_igemm_bf16x3_halo(const ConvParams p, const TileGeom g) {
 // MODE 2 (PP_FP8) is the declared non-parity fp8 form (kernels.h PREC_FP8): a chunk row holds 128 one-byte channels,
 // a K-step is 128 channels of one tap: 16 block-scaled MFMAs (K = 128 each), same staging and fragment reads.
 enum PpMode : int { PP_BF16X3 = 0, PP_F16X2 = 1, PP_FP8 = 2 };
-template <int EPI, int MODE>
+// ONE = true: the input has ONE 32-slot chunk (the Cin = 128 convs of the fp8 mode: 128 one-byte channels).  The
+// unrolled body of 18 K-steps then covers TWO work items (tiles) of 9 taps each instead of a chunk pair of one tile:
+// item B takes the place of "chunk 1" (its halo is staged during A's taps into the other halo buffer, its weights follow
+// A's in the weight ring), item A' of the next body the place of "the next tile"; A's epilogue runs between steps 8 and 9.
+// The LDS schedule is unchanged.  With an odd number of items the last body computes its item twice (same stores).
+template <int EPI, int MODE, bool ONE = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
     constexpr bool F16X2 = MODE == PP_F16X2;
@@ -1135,7 +1140,7 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
     // With p.ksplit > 1 (fewer tiles than CUs) a work item is (K range, tile): range ks covers chunk pairs
     // [ks * ppi, (ks + 1) * ppi), items are numbered range-major so that neighbours still share their halo.
     const int ksn = p.ksplit > 1 ? p.ksplit : 1;
-    const int ppi = (p.Cin / (2 * BKC)) / ksn;                                 // chunk pairs per item
+    const int ppi = ONE ? 1 : (p.Cin / (2 * BKC)) / ksn;                       // chunk pairs per item (ONE: one body = 2 items)
     const unsigned kbytes = (unsigned)ppi * 2u * BKC * 4u;                      // byte offset of one range (input and weights)
     const int items = g.tiles_mn * ksn;
     const int slots = gridDim.x >> 3, xcd = blockIdx.x & 7;
@@ -1198,6 +1203,8 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
         const_cast<float*>(p.wt), 0, (int)(9u * w_tap_bytes), 0x00020000);
     unsigned h_pair = 0, w_pair = 0;              // byte offsets of the current chunk pair
     unsigned h_next = 0, w_next = 0;              // byte offsets of the NEXT tile (of this one again on the last)
+    unsigned h_b = 0, w_b = 0;                    // ONE: the body's second item
+    int n0b = 0, tx0b = 0, ty0b = 0, b0b = 0, ksb = 0;
 
     float4 rh0, rh1, rh2, rh3, rh4, rh5;          // halo of the next chunk in flight
     float4 rw0, rw1;                              // weights of the next K-step in flight
@@ -1246,11 +1253,19 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
 #define MSR_R(T, LASTP)                                                                          \
     {                                                                                            \
         MSR_WRITE_B(((T) + 1) & 1);                                                              \
-        if ((LASTP) && (T) + 2 >= 18) MSR_LOAD_B(w_next + MSR_WOFF((T) + 2 - 18))                \
-        else MSR_LOAD_B(w_tile + w_pair + MSR_WOFF((T) + 2));                                    \
-        if ((T) % 9 == 1) {                                                                      \
-            if ((LASTP) && (T) >= 9) MSR_LOAD_H(h_next)                                          \
-            else MSR_LOAD_H(h_tile + h_pair + ((T) / 9 + 1) * BKC * 4);                          \
+        if constexpr (ONE) {                                                                     \
+            if ((T) + 2 >= 18) MSR_LOAD_B(w_next + (unsigned)((T) + 2 - 18) * w_tap_bytes)       \
+            else if ((T) + 2 >= 9) MSR_LOAD_B(w_b + (unsigned)((T) + 2 - 9) * w_tap_bytes)       \
+            else MSR_LOAD_B(w_tile + (unsigned)((T) + 2) * w_tap_bytes);                         \
+            if ((T) == 1) MSR_LOAD_H(h_b)                                                        \
+            if ((T) == 10) MSR_LOAD_H(h_next)                                                    \
+        } else {                                                                                 \
+            if ((LASTP) && (T) + 2 >= 18) MSR_LOAD_B(w_next + MSR_WOFF((T) + 2 - 18))            \
+            else MSR_LOAD_B(w_tile + w_pair + MSR_WOFF((T) + 2));                                \
+            if ((T) % 9 == 1) {                                                                  \
+                if ((LASTP) && (T) >= 9) MSR_LOAD_H(h_next)                                      \
+                else MSR_LOAD_H(h_tile + h_pair + ((T) / 9 + 1) * BKC * 4);                      \
+            }                                                                                    \
         }                                                                                        \
         /* the halo of the next chunk goes to LDS in two halves (taps 6 and 7): all six stores in one R make that   \
            segment longer than the partner's matrix segment (1060 vs 840 cycles) */              \
@@ -1321,7 +1336,12 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
     {                                                                                            \
         MSR_STAMP()                                                                              \
         MSR_R(T, LASTP)                                                                          \
-        if ((LASTP) && (T) == 16 && EPI != EPI_PARTIAL && MODE != PP_FP8) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0); \
+        if constexpr (ONE) {                                                                     \
+            if ((T) == 7 && MODE != PP_FP8) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0); \
+            if ((T) == 16 && MODE != PP_FP8) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0b, tx0b, ty0b + grp * 8, b0b); \
+        } else {                                                                                 \
+            if ((LASTP) && (T) == 16 && EPI != EPI_PARTIAL && MODE != PP_FP8) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0); \
+        }                                                                                        \
         MSR_STAMP()                                                                              \
         MSR_WG_BARRIER()                                                                         \
         MSR_STAMP()                                                                              \
@@ -1331,6 +1351,18 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
         MSR_STAMP()                                                                              \
         /* Y's M on the workgroup's very last step has no partner segment */                     \
         if (!((LASTP) && (T) == 17) || has_next || grp == 0) MSR_WG_BARRIER()                    \
+        if constexpr (ONE) {                                                                     \
+            if ((T) == 8) {   /* item A is complete: its epilogue, fresh accumulators, item B's weight scales */ \
+                if constexpr (MODE == PP_FP8) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0); \
+                halo16_epilogue<EPI>(p, ge, acc, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0, xpre, cpre); \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i)                                    \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                \
+                        _Pragma("unroll") for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;        \
+                if constexpr (MODE == PP_FP8) {                                                  \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) wsc[j] = p.wexp[n0b + wn * 64 + j * 16 + (lane & 15)]; \
+                }                                                                                \
+            }                                                                                    \
+        }                                                                                        \
     }
 #define MSR_PAIR(LASTP)                                                                          \
     MSR_STEP(0, LASTP) MSR_STEP(1, LASTP) MSR_STEP(2, LASTP) MSR_STEP(3, LASTP) MSR_STEP(4, LASTP) \
@@ -1356,10 +1388,14 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
     ge.th_l = 3;
     ge.tiles_y = g.tiles_y * 2;
     for (;;) {
-        const int tnext = tile + slots;
+        const int tnext = ONE ? tile + 2 * slots : tile + slots;
         const bool has_next = tnext < cnt;
         int n0n, tx0n, ty0n, b0n, ks0n;
         MSR_DECODE(base + (has_next ? tnext : tile), n0n, tx0n, ty0n, b0n, h_next, w_next, ks0n)
+        if constexpr (ONE) {
+            const int tb = tile + slots < cnt ? tile + slots : tile;      // no second item left: item A again
+            MSR_DECODE(base + tb, n0b, tx0b, ty0b, b0b, h_b, w_b, ksb)
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1388,9 +1424,14 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
         // Y beside X's first M of the next tile.  Its stores are not waited for.
         // PP_FP8: the scaled MFMA does not accumulate in place under register pressure, so its epilogue operands are
         // not held across the last K-steps but requested here
-        if constexpr (MODE == PP_FP8) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0);
-        if constexpr (EPI == EPI_PARTIAL) halo16_epilogue_partial(p, acc, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0, ks0);
-        else halo16_epilogue<EPI>(p, ge, acc, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0, xpre, cpre);
+        if constexpr (ONE) {       // the body's second item
+            if constexpr (MODE == PP_FP8) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0b, tx0b, ty0b + grp * 8, b0b);
+            halo16_epilogue<EPI>(p, ge, acc, wm, wn, lane, n0b, tx0b, ty0b + grp * 8, b0b, xpre, cpre);
+        } else {
+            if constexpr (MODE == PP_FP8) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0);
+            if constexpr (EPI == EPI_PARTIAL) halo16_epilogue_partial(p, acc, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0, ks0);
+            else halo16_epilogue<EPI>(p, ge, acc, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0, xpre, cpre);
+        }
         if (!has_next) break;
         tile = tnext;
         n0 = n0n; tx0 = tx0n; ty0 = ty0n; b0 = b0n; ks0 = ks0n;
@@ -1550,13 +1591,14 @@ static constexpr size_t PP_LDS = (size_t)(2 * 324 + 2 * 128) * 40 * sizeof(float
 
 static hipError_t set_attr_halo() {
     hipError_t e;
-#define MSR_SETPP(EPI, F16)                                                                                   \
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_pp<EPI, F16>),               \
+#define MSR_SETPP(EPI, ...)                                                                                   \
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_pp<EPI, __VA_ARGS__>),       \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_LDS)) != hipSuccess)      \
         return e;
     MSR_SETPP(EPI_BIAS, PP_BF16X3) MSR_SETPP(EPI_RES, PP_BF16X3) MSR_SETPP(EPI_SPADE, PP_BF16X3)
     MSR_SETPP(EPI_SPADE, PP_F16X2) MSR_SETPP(EPI_PARTIAL, PP_BF16X3)
     MSR_SETPP(EPI_BIAS, PP_FP8) MSR_SETPP(EPI_RES, PP_FP8) MSR_SETPP(EPI_SPADE, PP_FP8)
+    MSR_SETPP(EPI_BIAS, PP_FP8, true) MSR_SETPP(EPI_RES, PP_FP8, true) MSR_SETPP(EPI_SPADE, PP_FP8, true)
 #undef MSR_SETPP
 #define MSR_SET(EPI)                                                                                          \
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_halo<EPI, 0>),               \
@@ -1798,10 +1840,12 @@ static hipError_t launch_halo(const ConvParams& p, int epi, int sh, hipStream_t 
 static hipError_t launch_pp(const ConvParams& p, int epi, hipStream_t s) {
     TileGeom g;
     if (!make_geom(p, 256, 128, 32, g)) return hipErrorInvalidValue;
-    if (g.tb != 1 || g.th_l != 4 || g.tw_l != 4 || p.stride != 1 || p.KH != 3 || p.KW != 3 || p.Cin % 64)
+    const bool one = p.prec == PREC_FP8 && p.Cin == 32;            // one 128-byte chunk: two tiles per unrolled body
+    if (g.tb != 1 || g.th_l != 4 || g.tw_l != 4 || p.stride != 1 || p.KH != 3 || p.KW != 3 || (!one && p.Cin % 64))
         return hipErrorInvalidValue;
     const int ksn = p.ksplit > 1 ? p.ksplit : 1;
-    if ((p.Cin / 64) % ksn) return hipErrorInvalidValue;          // every K range is a whole number of chunk pairs
+    if (!one && (p.Cin / 64) % ksn) return hipErrorInvalidValue;  // every K range is a whole number of chunk pairs
+    if (one && ksn > 1) return hipErrorInvalidValue;
     if ((size_t)p.B * p.in_pb * sizeof(float) >= ((size_t)1 << 31)) return hipErrorInvalidValue;   // buffer descriptor range
     // persistent: one workgroup per CU (144 KB of LDS each), a multiple of 8 so that every XCD gets the same count
     static int n_cu = 0;
@@ -1834,6 +1878,15 @@ static hipError_t launch_pp(const ConvParams& p, int epi, hipStream_t s) {
     }
     if (p.prec == PREC_FP8) {
         if (!p.wexp) return hipErrorInvalidValue;
+        if (one) {
+            switch (epi) {
+                case EPI_BIAS: conv_igemm_bf16x3_pp<EPI_BIAS, PP_FP8, true><<<grid, 512, PP_LDS, s>>>(p, g); break;
+                case EPI_RES: conv_igemm_bf16x3_pp<EPI_RES, PP_FP8, true><<<grid, 512, PP_LDS, s>>>(p, g); break;
+                case EPI_SPADE: conv_igemm_bf16x3_pp<EPI_SPADE, PP_FP8, true><<<grid, 512, PP_LDS, s>>>(p, g); break;
+                default: return hipErrorInvalidValue;
+            }
+            return hipGetLastError();
+        }
         switch (epi) {
             case EPI_BIAS: conv_igemm_bf16x3_pp<EPI_BIAS, PP_FP8><<<grid, 512, PP_LDS, s>>>(p, g); break;
             case EPI_RES: conv_igemm_bf16x3_pp<EPI_RES, PP_FP8><<<grid, 512, PP_LDS, s>>>(p, g); break;

@@ -132,7 +132,7 @@ def fp8_weight_image(w_kl: torch.Tensor):
     fp32 weights) exactly as msr_load_weight quantises them for the fp8 mode: a power-of-two scale per output channel
     that puts the channel's largest |w| into e4m3's top binade."""
     taps, N, Cin = w_kl.shape
-    cpad = max(256, (Cin + 255) // 256 * 256)
+    cpad = 128 if Cin <= 128 else (Cin + 255) // 256 * 256
     amax = w_kl.abs().amax(dim=(0, 2)).double().cpu()
     e = torch.zeros(N, dtype=torch.int64)
     nz = amax > 0
@@ -149,7 +149,7 @@ def fp8_weight_image(w_kl: torch.Tensor):
 def bf8_activation_image(x_padded: torch.Tensor):
     """[B, r+2, r+2, C] fp32 -> (bf8 e5m2 bytes [B, r+2, r+2, Cpad] uint8, dequantised fp32 values)."""
     C_ = x_padded.shape[-1]
-    cpad = max(256, (C_ + 255) // 256 * 256)
+    cpad = 128 if C_ <= 128 else (C_ + 255) // 256 * 256
     q = x_padded.to(torch.float8_e5m2)
     img = torch.zeros(x_padded.shape[:-1] + (cpad,), dtype=torch.uint8, device=x_padded.device)
     img[..., :C_] = q.view(torch.uint8)
@@ -165,7 +165,7 @@ def conv3x3_fp8(ctx: OpContext, x_bytes: torch.Tensor, w_bytes: torch.Tensor, we
     N = w_bytes.shape[1]
     Cout = N // 2 if epilogue == EPI_SPADE else N
     if out_mode == 3:
-        opad = max(256, (Cout + 255) // 256 * 256)
+        opad = 128 if Cout <= 128 else (Cout + 255) // 256 * 256
         shape = (B, rout + 2, rout + 2, opad) if out_padded else (B, rout, rout, opad)
         out = torch.zeros(shape, dtype=torch.uint8, device=x_bytes.device)
     else:
