@@ -872,8 +872,10 @@ int plan_spade(msr_handle* h) {
                 snprintf(k, sizeof k, "gen.rb%d.spade_%d.gb.kernel.wexp", i, j);
                 gb.conv.prec = PREC_FP8;
                 gb.conv.wexp = reinterpret_cast<const int*>(need(k));
-                gb.flops = 2.0 * B * r * r * 128.0 * (2 * C) * 9;           // algorithmic (the padded channels are zeros)
-                if (gb.tile != TILE_256x128_PP || gb.conv.ksplit != 1) return fail(h, MSR_ERR_STATE, "fp8 plan: rb%d gb%d is not a whole-tile ping-pong launch", i, j);
+                gb.flops = 2.0 * B * r * r * 128.0 * (2 * C) * 9;
+                gb.tile = TILE_256x128_PP;            // gb_uses_fp8 checked that it fills the chip with whole tiles
+                gb.conv.ksplit = 1;
+                gb.conv.wt_frag = 0;
             }
             if (cv8) gb.conv.out_split = 3;           // its epilogue writes bf8 bytes for the fp8 consumer
             set_out_padded(gb.conv, ab);
@@ -890,7 +892,9 @@ int plan_spade(msr_handle* h) {
                 cv.conv.prec = PREC_FP8;
                 cv.conv.wexp = reinterpret_cast<const int*>(need(k));
                 cv.flops = 2.0 * B * r * r * (double)C * f * 9;
-                if (cv.tile != TILE_256x128_PP || cv.conv.ksplit != 1) return fail(h, MSR_ERR_STATE, "fp8 plan: rb%d conv_%d is not a whole-tile ping-pong launch", i, conv_idx);
+                cv.tile = TILE_256x128_PP;
+                cv.conv.ksplit = 1;
+                cv.conv.wt_frag = 0;
             }
             set_out_dense(cv.conv, y, r, f);
             if (epi == EPI_RES) set_aux_dense(cv.conv, res, res_r, f, res_shift);
