@@ -53,11 +53,12 @@ WORKLOADS = {
 }
 # MI355X_MICROARCH.md: dense MFMA peaks.  For bf16x3 every algorithmic product costs three bf16 MFMA products, so
 # the algorithmic ceiling is a third of the bf16 peak; `achieved` stays ALGORITHMIC FLOP/s in every mode.
-PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16x3_gbf16": 2500.0, "fp8": 5000.0}
+PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16x3_gbf16": 2500.0, "fp8": 5000.0, "f16c": 2500.0}
 # MFMA products per algorithmic product; the opt-in mode runs 2 in the gamma|beta convs (half of the FLOPs), 3 elsewhere
-MFMA_PER_PRODUCT = {"fp32": 1, "bf16x3": 3, "bf16x3_gbf16": 2.5, "fp8": 1}
+MFMA_PER_PRODUCT = {"fp32": 1, "bf16x3": 3, "bf16x3_gbf16": 2.5, "fp8": 1, "f16c": 2}
 DTYPE = {"fp32": "f32", "bf16x3": "bf16x3 (f32 in/out/accumulate)",
          "bf16x3_gbf16": "bf16x3, gamma|beta convs f16x2 (opt-in; f32 in/out/accumulate; 2-5e-4 rel L-inf, inside the 1e-3 bar)",
+         "f16c": "f16 main term + fp8 cross terms in the chip-filling convs, bf16x3 elsewhere (f32 in/out/accumulate; parity mode)",
          "fp8": "fp8 e4m3 weights x bf8 e5m2 activations in the chip-filling convs, bf16x3 elsewhere (DECLARED NON-PARITY: "
                 "BASELINE configs[4]; f32 in/out/accumulate; error stated in tests/test_gpu_baseline_configs.py)"}
 
@@ -397,7 +398,8 @@ def main():
                        with_b1=solo and not args.no_also)
     if solo and not args.no_also:
         also = {}
-        for wl, prec in (("spade512", "bf16x3_gbf16"), ("spade512", "fp8"), ("spade256", "bf16x3"), ("spade256", "fp32")):
+        for wl, prec in (("spade512", "f16c"), ("spade512", "bf16x3_gbf16"), ("spade512", "fp8"), ("spade256", "bf16x3"),
+                         ("spade256", "fp32")):
             if (wl, prec) == (args.workload, args.precision):
                 continue
             r = run_workload(args, D, wl, prec, with_cpu=False, with_b1=False)

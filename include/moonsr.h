@@ -76,6 +76,13 @@ typedef struct {
  *                     bits per operand.  Its error against the float64 oracle is measured and stated in
  *                     tests/test_gpu_baseline_configs.py; it does NOT meet the 1e-3 bar and is never the default. */
 #define MSR_FLAG_FP8 4
+/*   MSR_FLAG_BF16X3 | MSR_FLAG_F16C   the same layers as MSR_FLAG_FP8 covers, on "fp16 main term + fp8 cross terms":
+ *                     a*b = a_hi*b_hi (v_mfma_f32_16x16x32_f16, exact products) + (a_hi*b_lo + a_lo*b_hi) on the block-scaled fp8
+ *                     MFMA (the cross terms are 2^-11 of the product, so 4 bits of them suffice; K = 128 covers both cross
+ *                     terms of two taps per instruction at twice the bf16 rate): two MFMA-equivalents per product instead
+ *                     of three, per-product error ~2^-15, 3-5e-5 relative L-inf end to end — a parity mode
+ *                     (tests/test_gpu_baseline_configs.py). */
+#define MSR_FLAG_F16C 8
 
 typedef struct msr_handle msr_handle;
 
@@ -247,6 +254,13 @@ int msr_op_conv3x3_bf16x3(msr_handle* h, const float* in_dev, const float* wt_de
                           float* out_dev, int32_t B, int32_t rout, int32_t Cin, int32_t N, int32_t stride,
                           int32_t epilogue, const float* aux_dev, int32_t aux_shift, const float* mean_dev,
                           const float* std_dev, int32_t out_padded, int32_t out_split, int32_t tile, void* stream);
+/* Kernel-level entry of the f16c form (MSR_FLAG_F16C) of the persistent ping-pong conv: in_dev / wt_dev hold f16c chunk
+ * images (moonsuperresolution_amd.ops.f16c_activation_image / f16c_weight_image restate the format), wexp_dev [N] =
+ * (127 + e_lo) | (127 + e_hi) << 8; out_mode (SPADE epilogue) 0 = fp32, 1 = split-bf16 words, 4 = f16c image. */
+int msr_op_conv3x3_f16c(msr_handle* h, const float* in_dev, const float* wt_dev, const int32_t* wexp_dev,
+                        const float* bias_dev, float* out_dev, int32_t B, int32_t rout, int32_t Cin, int32_t N,
+                        int32_t epilogue, const float* aux_dev, int32_t aux_shift, const float* mean_dev,
+                        const float* std_dev, int32_t out_padded, int32_t out_mode, void* stream);
 /* HOST helper: the fp32 -> fp8 e4m3 (OCP "fn", round to nearest even, saturating at 448) conversion msr_load_weight
  * applies to the weights of the fp8 mode, exposed so that it can be checked against an independent implementation. */
 int64_t msr_quantize_e4m3(const float* host, int64_t n, uint8_t* out);

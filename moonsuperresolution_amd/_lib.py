@@ -19,7 +19,8 @@ MSR_ERR_NOMEM = -4
 VARIANT_IDS = {"gaugan": 0, "gaugan_no_kl": 1, "cnn": 2, "pix2pix": 3}
 # msr_config.flags: MSR_FLAG_BF16X3 = 1, MSR_FLAG_GB_F16X2 = 2 (opt-in 2-term fp16 products in the gamma|beta convs)
 # MSR_FLAG_FP8 = 4: declared non-parity mode (fp8 weights x bf8 activations in the chip-filling convs)
-PRECISION_FLAGS = {"fp32": 0, "bf16x3": 1, "bf16x3_gbf16": 3, "fp8": 5}
+# MSR_FLAG_F16C = 8: fp16 main term + fp8 cross terms in the chip-filling convs (parity-grade, 2 MFMA-equivalents per product)
+PRECISION_FLAGS = {"fp32": 0, "bf16x3": 1, "bf16x3_gbf16": 3, "fp8": 5, "f16c": 9}
 
 
 class MsrConfig(C.Structure):
@@ -68,6 +69,8 @@ SYMBOLS = [
                                  _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P]),
     ("msr_op_conv3x3_bf16x3", C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    ("msr_op_conv3x3_f16c", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P,
+                                      C.c_int32, _P, _P, C.c_int32, C.c_int32, _P]),
     ("msr_quantize_e4m3", C.c_int64, [_P, C.c_int64, _P]),
     ("msr_op_conv3x3_fp8", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P,
                                      C.c_int32, _P, _P, C.c_int32, C.c_int32, _P]),

@@ -62,6 +62,7 @@ struct msr_handle {
     int prec = 0;                                // PREC_F32 or PREC_BF16X3 (cfg.flags & MSR_FLAG_BF16X3)
     bool gb_f16x2 = false;                       // MSR_FLAG_GB_F16X2: 2-term fp16 products in the gamma|beta convs
     bool fp8 = false;                            // MSR_FLAG_FP8: declared non-parity mode (fp8 weights x bf8 activations)
+    bool f16c = false;                           // MSR_FLAG_F16C: fp16 main term + fp8 cross terms in the chip-filling convs
     std::string err;
     std::vector<WeightSpec> specs;
     std::map<std::string, int> spec_index;
@@ -309,6 +310,56 @@ bool main_uses_fp8(msr_handle* h, int rout, int cin, int cout) {
 }
 
 int upload(msr_handle* h, const std::string& key, const float* host, size_t floats);
+// MSR_FLAG_F16C: same coverage rule as the fp8 mode (whole-tile ping-pong launches; a main conv only if the gamma|beta
+// conv that writes its input is one too)
+bool gb_uses_f16c(msr_handle* h, int rout, int C) { return h->f16c && conv_fills_pp(h->B, rout, 2 * C); }
+bool main_uses_f16c(msr_handle* h, int rout, int cin, int cout) {
+    return h->f16c && cin % 64 == 0 && conv_fills_pp(h->B, rout, cout) && conv_fills_pp(h->B, rout, 2 * cin);
+}
+
+// f16c image of [taps][N][Cin] weights (kernels.h PREC_F16C): per 32-channel chunk [32 x hi f16 | l8 ch 0-15 | h8 ch 0-15 |
+// l8 ch 16-31 | h8 ch 16-31] with hi = f16_rn(w), l8 = e4m3((w - hi) * 2^-el), h8 = e4m3(w * 2^-eh), el / eh powers of two
+// per output channel; key + ".wexp"[n] = (127 + el) | (127 + eh) << 8
+int upload_conv_weight_f16c(msr_handle* h, const std::string& key, const float* host, int taps, int N, int Cin) {
+    if (Cin % 32) return fail(h, MSR_ERR_INVALID, "%s: f16c needs Cin %% 32 == 0", key.c_str());
+    std::vector<float> img((size_t)taps * N * Cin);
+    std::vector<int> wexp(N);
+    auto pow2exp = [](float amax) {
+        if (!(amax > 0.f)) return 0;
+        int fe;
+        (void)std::frexp(amax / 448.f, &fe);
+        return std::max(-100, std::min(100, fe));
+    };
+    for (int n = 0; n < N; ++n) {
+        float ah = 0.f, al = 0.f;
+        for (int t = 0; t < taps; ++t)
+            for (int k = 0; k < Cin; ++k) {
+                const float w = host[((size_t)t * N + n) * Cin + k];
+                const float hi = (float)(_Float16)w;
+                ah = std::max(ah, std::fabs(w));
+                al = std::max(al, std::fabs(w - hi));
+            }
+        const int eh = pow2exp(ah), el = pow2exp(al);
+        const float ih = std::ldexp(1.f, -eh), il = std::ldexp(1.f, -el);
+        wexp[n] = (127 + el) | ((127 + eh) << 8);
+        for (int t = 0; t < taps; ++t)
+            for (int c0 = 0; c0 < Cin; c0 += 32) {
+                unsigned char* chunk = reinterpret_cast<unsigned char*>(img.data() + ((size_t)t * N + n) * Cin + c0);
+                for (int c = 0; c < 32; ++c) {
+                    const float w = host[((size_t)t * N + n) * Cin + c0 + c];
+                    const _Float16 hi = (_Float16)w;
+                    reinterpret_cast<_Float16*>(chunk)[c] = hi;
+                    unsigned char* piece = chunk + 64 + 32 * (c >> 4) + (c & 15);     // l8 piece, h8 piece 16 bytes on
+                    piece[0] = msr_f32_to_e4m3((w - (float)hi) * il);
+                    piece[16] = msr_f32_to_e4m3(w * ih);
+                }
+            }
+    }
+    int rc = upload(h, key, img.data(), img.size());
+    if (rc) return rc;
+    return upload(h, key + ".wexp", reinterpret_cast<const float*>(wexp.data()), wexp.size());
+}
+
 // fp8 e4m3 image of [taps][N][Cin] weights: bytes [taps][N][fp8_pad(Cin)] (zero padded), a power-of-two scale per output
 // channel chosen so that the largest |w| of the channel lands in e4m3's top binade, its e8m0 exponent replicated in
 // the four bytes of key + ".wexp"[n]
@@ -438,6 +489,9 @@ int msr_create(const msr_config* cfg, msr_handle** out) {
     if ((cfg->flags & MSR_FLAG_FP8) && (!(cfg->flags & MSR_FLAG_BF16X3) || (cfg->flags & MSR_FLAG_GB_F16X2)))
         return fail(nullptr, MSR_ERR_INVALID, "MSR_FLAG_FP8 goes with MSR_FLAG_BF16X3 alone (the layers it does not cover run bf16x3)");
     h->fp8 = (cfg->flags & MSR_FLAG_FP8) && cfg->variant != MSR_PIX2PIX;
+    if ((cfg->flags & MSR_FLAG_F16C) && (!(cfg->flags & MSR_FLAG_BF16X3) || (cfg->flags & (MSR_FLAG_GB_F16X2 | MSR_FLAG_FP8))))
+        return fail(nullptr, MSR_ERR_INVALID, "MSR_FLAG_F16C goes with MSR_FLAG_BF16X3 alone (the layers it does not cover run bf16x3)");
+    h->f16c = (cfg->flags & MSR_FLAG_F16C) && cfg->variant != MSR_PIX2PIX;
     if (cfg->variant == MSR_PIX2PIX) { h->prec = PREC_F32; h->gb_f16x2 = false; }   // the parity config runs on the fp32 MFMA
     build_specs(h.get());
     *out = h.release();
@@ -601,6 +655,7 @@ int msr_load_weight(msr_handle* h, const char* name_c, const float* host, const 
             int rout = 0, stride = 1;
             weight_conv_shape(h, name, &rout, &stride);
             if (gb_uses_fp8(h, rout, C)) rc = upload_conv_weight_fp8(h, base + ".gb.kernel", img.data(), 9, 2 * C, cin);
+            else if (gb_uses_f16c(h, rout, C)) rc = upload_conv_weight_f16c(h, base + ".gb.kernel", img.data(), 9, 2 * C, cin);
             else
                 rc = upload_conv_weight(h, base + ".gb.kernel", img.data(), img.size(), 9, 2 * C, cin,
                                         weight_uses_frag(h, name, 2 * C, EPI_SPADE, cin), gb_uses_f16x2(h, rout, 2 * C, cin));
@@ -619,8 +674,9 @@ int msr_load_weight(msr_handle* h, const char* name_c, const float* host, const 
         std::vector<float> t(count);
         hwio_to_tap_oc_ic(host, t.data(), taps, cin, cout, cout, nullptr);
         int rout = 0, stride = 1;
-        if (name.rfind("gen.rb", 0) == 0 && weight_conv_shape(h, name, &rout, &stride) && main_uses_fp8(h, rout, cin, cout))
-            rc = upload_conv_weight_fp8(h, name, t.data(), taps, cout, cin);
+        const bool gen_conv = name.rfind("gen.rb", 0) == 0 && weight_conv_shape(h, name, &rout, &stride);
+        if (gen_conv && main_uses_fp8(h, rout, cin, cout)) rc = upload_conv_weight_fp8(h, name, t.data(), taps, cout, cin);
+        else if (gen_conv && main_uses_f16c(h, rout, cin, cout)) rc = upload_conv_weight_f16c(h, name, t.data(), taps, cout, cin);
         else
             rc = upload_conv_weight(h, name, t.data(), count, taps, cout, cin, weight_uses_frag(h, name, cout, EPI_BIAS, cin));
     } else {
@@ -845,6 +901,7 @@ int plan_spade(msr_handle* h) {
             // MSR_FLAG_FP8: tensors that feed an fp8 conv hold one byte per channel, padded to 256 channels; the kernels
             // address them in float slots of 4 channels
             const bool gb8 = gb_uses_fp8(h, r, C), cv8 = main_uses_fp8(h, r, C, f);
+            const bool gbc = gb_uses_f16c(h, r, C), cvc = main_uses_f16c(h, r, C, f);
             const int hslots = gb8 ? fp8_pad(128) / 4 : 128, aslots = cv8 ? fp8_pad(C) / 4 : C;
             snprintf(k, sizeof k, "ws.gen.rb%d.h%d", i, j); int rc2 = alloc_padded(h, k, r, hslots, &hb); if (rc2) return rc2;
             snprintf(k, sizeof k, "ws.gen.rb%d.a%d", i, j); rc2 = alloc_padded(h, k, r, aslots, &ab); if (rc2) return rc2;
@@ -857,7 +914,7 @@ int plan_spade(msr_handle* h) {
             p.out_px = hslots; p.out_py = hb.py(); p.out_pb = hb.pb(); p.out_off = hb.interior();
             p.act = 1; p.slope = 0.f;
             const bool f16x2 = gb_uses_f16x2(h, r, 2 * C, 128);
-            p.out_split = gb8 ? 3 : f16x2 ? 2 : (h->prec == PREC_BF16X3 ? 1 : 0);
+            p.out_split = gb8 ? 3 : gbc ? 4 : f16x2 ? 2 : (h->prec == PREC_BF16X3 ? 1 : 0);
             em.flops = 2.0 * B * r * r * 18.0 * 128;
             em.on_aux = true;
             em.aux_group = i <= 4 ? 0 : 1;        // rb1-4 embeds are small and done early; rb5-6 carry the bytes
@@ -877,7 +934,16 @@ int plan_spade(msr_handle* h) {
                 gb.conv.ksplit = 1;
                 gb.conv.wt_frag = 0;
             }
+            if (gbc) {
+                snprintf(k, sizeof k, "gen.rb%d.spade_%d.gb.kernel.wexp", i, j);
+                gb.conv.prec = PREC_F16C;
+                gb.conv.wexp = reinterpret_cast<const int*>(need(k));
+                gb.tile = TILE_256x128_PP;
+                gb.conv.ksplit = 1;
+                gb.conv.wt_frag = 0;
+            }
             if (cv8) gb.conv.out_split = 3;           // its epilogue writes bf8 bytes for the fp8 consumer
+            if (cvc) gb.conv.out_split = 4;           // ... the f16c chunk image for the f16c consumer
             set_out_padded(gb.conv, ab);
             set_aux_dense(gb.conv, x, rx, C, xshift);
             gb.conv.mean = mean; gb.conv.stdv = stdv;
@@ -892,6 +958,14 @@ int plan_spade(msr_handle* h) {
                 cv.conv.prec = PREC_FP8;
                 cv.conv.wexp = reinterpret_cast<const int*>(need(k));
                 cv.flops = 2.0 * B * r * r * (double)C * f * 9;
+                cv.tile = TILE_256x128_PP;
+                cv.conv.ksplit = 1;
+                cv.conv.wt_frag = 0;
+            }
+            if (cvc) {
+                snprintf(k, sizeof k, "gen.rb%d.conv_%d.kernel.wexp", i, conv_idx);
+                cv.conv.prec = PREC_F16C;
+                cv.conv.wexp = reinterpret_cast<const int*>(need(k));
                 cv.tile = TILE_256x128_PP;
                 cv.conv.ksplit = 1;
                 cv.conv.wt_frag = 0;
@@ -1393,6 +1467,36 @@ int msr_op_conv3x3_bf16x3(msr_handle* h, const float* in_dev, const float* wt_de
     if ((tile & 0x3F) == TILE_128x128_K16) return fail(h, MSR_ERR_INVALID, "the bf16x3 path has no 16-channel K-step tile");
     return op_conv_impl(h, in_dev, wt_dev, bias_dev, out_dev, B, rout, Cin, N, stride, epilogue, aux_dev, aux_shift,
                         mean_dev, std_dev, out_padded, tile, PREC_BF16X3, out_split, stream);
+}
+
+int msr_op_conv3x3_f16c(msr_handle* h, const float* in_dev, const float* wt_dev, const int32_t* wexp_dev,
+                        const float* bias_dev, float* out_dev, int32_t B, int32_t rout, int32_t Cin, int32_t N,
+                        int32_t epilogue, const float* aux_dev, int32_t aux_shift, const float* mean_dev,
+                        const float* std_dev, int32_t out_padded, int32_t out_mode, void* stream) {
+    if (!h) return MSR_ERR_INVALID;
+    if (!in_dev || !wt_dev || !wexp_dev || !bias_dev || !out_dev || B < 1 || rout < 16 || Cin % 64 || N % 128)
+        return fail(h, MSR_ERR_INVALID, "msr_op_conv3x3_f16c: bad argument (Cin %% 64, N %% 128, rout >= 16)");
+    if (epilogue < EPI_BIAS || epilogue > EPI_SPADE || (epilogue != EPI_BIAS && !aux_dev) ||
+        (epilogue == EPI_SPADE && (!mean_dev || !std_dev)) || (out_mode != 0 && out_mode != 1 && out_mode != 4) ||
+        (out_mode != 0 && epilogue != EPI_SPADE))
+        return fail(h, MSR_ERR_INVALID, "msr_op_conv3x3_f16c: bad epilogue / output mode");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    Padded in; in.base = const_cast<float*>(in_dev); in.r = rout; in.C = Cin;
+    Op op = conv_op(in, wt_dev, bias_dev, B, rout, N, 1, epilogue, PREC_BF16X3);
+    op.tile = TILE_256x128_PP;
+    op.conv.ksplit = 1;
+    op.conv.wt_frag = 0;
+    op.conv.prec = PREC_F16C;
+    op.conv.wexp = wexp_dev;
+    op.conv.out_split = epilogue == EPI_SPADE ? out_mode : 0;
+    const int Cout = epilogue == EPI_SPADE ? N / 2 : N;
+    if (out_padded) { Padded o; o.base = out_dev; o.r = rout; o.C = Cout; set_out_padded(op.conv, o); }
+    else set_out_dense(op.conv, out_dev, rout, Cout);
+    if (epilogue != EPI_BIAS) set_aux_dense(op.conv, aux_dev, rout >> aux_shift, Cout, aux_shift);
+    op.conv.mean = mean_dev; op.conv.stdv = std_dev;
+    hipError_t e = launch_conv_igemm(op.conv, epilogue, op.tile, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(h, MSR_ERR_INVALID, "f16c conv launch rejected: %s", hipGetErrorString(e));
+    return MSR_OK;
 }
 
 int64_t msr_quantize_e4m3(const float* host, int64_t n, uint8_t* out) {

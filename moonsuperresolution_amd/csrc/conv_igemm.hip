@@ -304,7 +304,7 @@ __device__ __forceinline__ void halo16_epilogue_partial(const ConvParams& p, f32
             *reinterpret_cast<float4*>(pbase + (size_t)(y0 + i) * p.Wout * p.N + j * 16) = f4(acc[i][j]);
 }
 
-template <int EPI, bool SPLIT, bool OUT8 = false>
+template <int EPI, bool SPLIT, bool OUT8 = false, bool OUTC = false>
 __device__ __forceinline__ void halo16_epilogue_body(const ConvParams& p, f32x4 (&acc)[4][4], int wm, int wn, int lane,
                                                      int n0, int tx0, int ty0, int b0, int stat_tile,
                                                      float4 (&xin)[4][2], float4 (&cv)[8]) {
@@ -336,7 +336,9 @@ __device__ __forceinline__ void halo16_epilogue_body(const ConvParams& p, f32x4 
                     const float t = (acc[i][jj][k] + gq[k]) * normalized + (acc[i][jj + 2][k] + bq[k]);
                     v[k] = t >= 0.f ? t : t * p.slope;
                 }
-                if constexpr (OUT8) {
+                if constexpr (OUTC) {
+                    msr_store_f16c4_dev(orow, ch0 + jj * 16 + 4 * cg, v[0], v[1], v[2], v[3]);   // PREC_F16C consumer
+                } else if constexpr (OUT8) {
                     // bf8 e5m2 bytes for a PREC_FP8 consumer: 4 consecutive channels = one dword
                     unsigned w8 = 0;
                     w8 = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], w8, false);
@@ -408,7 +410,8 @@ __device__ __forceinline__ void halo16_epilogue(const ConvParams& p, const TileG
                                                 float4 (&cv)[8]) {
     const int stat_tile = (b0 * g.tiles_y + (ty0 >> g.th_l)) * g.tiles_x + (tx0 >> g.tw_l);
     if constexpr (EPI == EPI_SPADE) {
-        if (p.out_split == 3) halo16_epilogue_body<EPI, true, true>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile, xin, cv);
+        if (p.out_split == 4) halo16_epilogue_body<EPI, true, false, true>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile, xin, cv);
+        else if (p.out_split == 3) halo16_epilogue_body<EPI, true, true>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile, xin, cv);
         else if (p.out_split) halo16_epilogue_body<EPI, true>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile, xin, cv);
         else halo16_epilogue_body<EPI, false>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile, xin, cv);
     } else {
@@ -1108,7 +1111,14 @@ conv_igemm_bf16x3_halo(const ConvParams p, const TileGeom g) {
 // instead of 48 and 16.
 // MODE 2 (PP_FP8) is the declared non-parity fp8 form (kernels.h PREC_FP8): a chunk row holds 128 one-byte channels,
 // a K-step is 128 channels of one tap: 16 block-scaled MFMAs (K = 128 each), same staging and fragment reads.
-enum PpMode : int { PP_BF16X3 = 0, PP_F16X2 = 1, PP_FP8 = 2 };
+// MODE 3 (PP_F16C, kernels.h PREC_F16C): fp16 main term + fp8 cross terms.  A chunk row holds [32 x hi f16 | four 16-byte
+// pieces: h8 ch 0-15, l8 ch 0-15, h8 ch 16-31, l8 ch 16-31] (weights: l8 / h8 swapped so that piece g of one pairs with
+// piece g of the other: w_lo*x_hi, w_hi*x_lo).  Every K-step runs the 16 f16 MFMAs of its tap (x_hi * w_hi); the lane's
+// piece (16 bytes at +64 + 16 * (lane >> 4): the same conflict-free read as the bf16 lo half) of an EVEN step and of the
+// following ODD step make one 32-byte operand, and the odd step adds 16 block-scaled K = 128 fp8 MFMAs that cover the
+// cross terms of both taps, each lane's e8m0 scale selecting its piece's scale (hi or lo).  Two MFMA-equivalents per
+// product instead of three; per-product error ~2^-15 (the fp8 rounding of a term that is 2^-11 of the product).
+enum PpMode : int { PP_BF16X3 = 0, PP_F16X2 = 1, PP_FP8 = 2, PP_F16C = 3 };
 // ONE = true: the input has ONE 32-slot chunk (the Cin = 128 convs of the fp8 mode: 128 one-byte channels).  The
 // unrolled body of 18 K-steps then covers TWO work items (tiles) of 9 taps each instead of a chunk pair of one tile:
 // item B takes the place of "chunk 1" (its halo is staged during A's taps into the other halo buffer, its weights follow
@@ -1210,6 +1220,8 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
     float4 rw0, rw1;                              // weights of the next K-step in flight
     bf16x8 ah[4], al[4], bh[4], bl[4];            // fragments of the current K-step
     i32x8 qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3; // ... PP_FP8: the same 32 bytes per lane as ONE 8-register operand
+    i32x4 ca0[4], ca1[4], cb0[4], cb1[4];         // ... PP_F16C: the cross-term pieces of an even step and of the odd one after it
+    const int asc = ((lane >> 4) & 1) ? 0x74747474 : 0x7F7F7F7F;   // PP_F16C: e8m0 of the activation piece: l8 = x_lo * 2^11 (116), h8 = x_hi (127)
     float4 xpre[4][2], cpre[8];                   // the epilogue's memory operands, requested on step 16 of the last pair
 #define MSR_BUFLD(rs, voff, soff) \
     __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (int)(soff), 0))
@@ -1277,6 +1289,18 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
             /* the K = 128 MFMA takes 8 consecutive registers per operand: both 16-byte halves into one vector */ \
             MSR_RD8(qa0, a_ + a_frag[0]) MSR_RD8(qa1, a_ + a_frag[1]) MSR_RD8(qa2, a_ + a_frag[2]) MSR_RD8(qa3, a_ + a_frag[3]) \
             MSR_RD8(qb0, b_ + b_frag[0]) MSR_RD8(qb1, b_ + b_frag[1]) MSR_RD8(qb2, b_ + b_frag[2]) MSR_RD8(qb3, b_ + b_frag[3]) \
+        } else if constexpr (MODE == PP_F16C) {                                                  \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                      \
+                ah[i] = *reinterpret_cast<const bf16x8*>(a_ + a_frag[i]);                        \
+                bh[i] = *reinterpret_cast<const bf16x8*>(b_ + b_frag[i]);                        \
+                if (((T) & 1) == 0) {                                                            \
+                    ca0[i] = *reinterpret_cast<const i32x4*>(a_ + a_frag[i] + 16);               \
+                    cb0[i] = *reinterpret_cast<const i32x4*>(b_ + b_frag[i] + 16);               \
+                } else {                                                                         \
+                    ca1[i] = *reinterpret_cast<const i32x4*>(a_ + a_frag[i] + 16);               \
+                    cb1[i] = *reinterpret_cast<const i32x4*>(b_ + b_frag[i] + 16);               \
+                }                                                                                \
+            }                                                                                    \
         } else {                                                                                 \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                      \
                 ah[i] = *reinterpret_cast<const bf16x8*>(a_ + a_frag[i]);                        \
@@ -1299,8 +1323,26 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
     acc[2][J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(WQ, qa2, acc[2][J], 0, 1, 0, wsc[J], 0, 0x7F7F7F7F); \
     acc[3][J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(WQ, qa3, acc[3][J], 0, 1, 0, wsc[J], 0, 0x7F7F7F7F);
 #define MSR_F16(v) __builtin_bit_cast(f16x8, v)
-#define MSR_M()                                                                                  \
-    if constexpr (MODE == PP_FP8) {                                                              \
+#define MSR_CAT8(lo, hi) __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)
+#define MSR_M(T)                                                                                 \
+    if constexpr (MODE == PP_F16C) {                                                             \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                          \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                        \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(MSR_F16(bh[j]), MSR_F16(ah[i]), acc[i][j], 0, 0, 0); \
+        }                                                                                        \
+        if (((T) & 1) == 1) {                                                                    \
+            /* the cross MFMA of an accumulator 16 instructions after its main one: no dependent-issue stall */ \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                      \
+                const i32x8 wq_ = MSR_CAT8(cb0[j], cb1[j]);                                      \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i)                                    \
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wq_, MSR_CAT8(ca0[i], ca1[i]), acc[i][j], \
+                                                                                 0, 0, 0, wsc[j], 0, asc); \
+            }                                                                                    \
+        }                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));     \
+    } else if constexpr (MODE == PP_FP8) {                                                       \
         /* weights fp8 e4m3 (row operand, per-channel e8m0 scale in wsc[j]) x activations bf8 e5m2 (unit scale) */ \
         MSR_MF8(0, qb0) MSR_MF8(1, qb1) MSR_MF8(2, qb2) MSR_MF8(3, qb3)                          \
         /* pin the accumulators here: without a use in this segment LLVM sinks the whole MFMA chain of the last chunk  \
@@ -1340,13 +1382,13 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
             if ((T) == 7 && MODE != PP_FP8) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0); \
             if ((T) == 16 && MODE != PP_FP8) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0b, tx0b, ty0b + grp * 8, b0b); \
         } else {                                                                                 \
-            if ((LASTP) && (T) == 16 && EPI != EPI_PARTIAL && MODE != PP_FP8) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0); \
+            if ((LASTP) && (T) == 16 && EPI != EPI_PARTIAL && MODE != PP_FP8 && MODE != PP_F16C) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0); \
         }                                                                                        \
         MSR_STAMP()                                                                              \
         MSR_WG_BARRIER()                                                                         \
         MSR_STAMP()                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        MSR_M()                                                                                  \
+        MSR_M(T)                                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         MSR_STAMP()                                                                              \
         /* Y's M on the workgroup's very last step has no partner segment */                     \
@@ -1406,6 +1448,13 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) wsc[j] = p.wexp[n0 + wn * 64 + j * 16 + (lane & 15)];
         }
+        if constexpr (MODE == PP_F16C) {    // byte 0 = e8m0 of the channel's w_lo pieces (even lane groups), byte 1 = of its w_hi pieces
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int w_ = p.wexp[n0 + wn * 64 + j * 16 + (lane & 15)];
+                wsc[j] = ((((lane >> 4) & 1) ? (w_ >> 8) : w_) & 0xFF) * 0x01010101;
+            }
+        }
         h_pair = 0;
         w_pair = 0;
         for (int pr = 0; pr < ppi - 1; ++pr) {
@@ -1428,7 +1477,7 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
             if constexpr (MODE == PP_FP8) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0b, tx0b, ty0b + grp * 8, b0b);
             halo16_epilogue<EPI>(p, ge, acc, wm, wn, lane, n0b, tx0b, ty0b + grp * 8, b0b, xpre, cpre);
         } else {
-            if constexpr (MODE == PP_FP8) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0);
+            if constexpr (MODE == PP_FP8 || MODE == PP_F16C) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0);
             if constexpr (EPI == EPI_PARTIAL) halo16_epilogue_partial(p, acc, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0, ks0);
             else halo16_epilogue<EPI>(p, ge, acc, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0, xpre, cpre);
         }
@@ -1461,6 +1510,7 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
 #undef MSR_R
 #undef MSR_M
 #undef MSR_F16
+#undef MSR_CAT8
 #undef MSR_RD8
 #undef MSR_MF8
 #undef MSR_STEP
@@ -1599,6 +1649,7 @@ static hipError_t set_attr_halo() {
     MSR_SETPP(EPI_SPADE, PP_F16X2) MSR_SETPP(EPI_PARTIAL, PP_BF16X3)
     MSR_SETPP(EPI_BIAS, PP_FP8) MSR_SETPP(EPI_RES, PP_FP8) MSR_SETPP(EPI_SPADE, PP_FP8)
     MSR_SETPP(EPI_BIAS, PP_FP8, true) MSR_SETPP(EPI_RES, PP_FP8, true) MSR_SETPP(EPI_SPADE, PP_FP8, true)
+    MSR_SETPP(EPI_BIAS, PP_F16C) MSR_SETPP(EPI_RES, PP_F16C) MSR_SETPP(EPI_SPADE, PP_F16C)
 #undef MSR_SETPP
 #define MSR_SET(EPI)                                                                                          \
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_halo<EPI, 0>),               \
@@ -1876,6 +1927,16 @@ static hipError_t launch_pp(const ConvParams& p, int epi, hipStream_t s) {
         conv_igemm_bf16x3_pp<EPI_SPADE, PP_F16X2><<<grid, 512, PP_LDS, s>>>(p, g);
         return hipGetLastError();
     }
+    if (p.prec == PREC_F16C) {
+        if (!p.wexp) return hipErrorInvalidValue;
+        switch (epi) {
+            case EPI_BIAS: conv_igemm_bf16x3_pp<EPI_BIAS, PP_F16C><<<grid, 512, PP_LDS, s>>>(p, g); break;
+            case EPI_RES: conv_igemm_bf16x3_pp<EPI_RES, PP_F16C><<<grid, 512, PP_LDS, s>>>(p, g); break;
+            case EPI_SPADE: conv_igemm_bf16x3_pp<EPI_SPADE, PP_F16C><<<grid, 512, PP_LDS, s>>>(p, g); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     if (p.prec == PREC_FP8) {
         if (!p.wexp) return hipErrorInvalidValue;
         if (one) {
@@ -1905,7 +1966,7 @@ static hipError_t launch_pp(const ConvParams& p, int epi, hipStream_t s) {
 }
 
 hipError_t launch_conv_igemm(const ConvParams& p, int epilogue, int tile, hipStream_t s) {
-    if (p.prec == PREC_F16X2 || p.prec == PREC_FP8)
+    if (p.prec == PREC_F16X2 || p.prec == PREC_FP8 || p.prec == PREC_F16C)
         return tile == TILE_256x128_PP ? launch_pp(p, epilogue, s) : hipErrorInvalidValue;
     if (p.prec == PREC_BF16X3) {
         if (tile == TILE_256x128_PP) return launch_pp(p, epilogue, s);

@@ -48,7 +48,8 @@ struct ConvParams {
     int prec;                     // PREC_F32: operands are fp32; PREC_BF16X3: operands are split-bf16 words
     int out_split;                // EPI_SPADE only: 1 = write the split-bf16 image (the consumer conv runs PREC_BF16X3 / its
                                   // fp16 twin decided by the producer of the mask embedding), 3 = write bf8 e5m2 bytes
-                                  // (PREC_FP8 consumer: one byte per channel, dword index = channel / 4)
+                                  // (PREC_FP8 consumer: one byte per channel, dword index = channel / 4), 4 = the f16c
+                                  // chunk image (PREC_F16C consumer)
     float* stat_partial;          // EPI_BIAS / EPI_RES, ksplit == 1: per-wave partial moments of the OUTPUT,
                                   // [P][3][N] = (count, mean, M2) per 32- or 64-row slab (P = conv_stat_slabs)
     const int* wexp;              // PREC_FP8: [N] e8m0 exponent of every output channel's weight scale, replicated in the
@@ -71,7 +72,14 @@ struct ConvParams {
 // block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 (128 channels of one tap per instruction, twice the bf16 rate); the
 // per-channel weight scale rides in the instruction's e8m0 scale operand, fp32 accumulation.  Tensors hold one byte per
 // channel; the kernel sees them as float slots of 4 channels (Cin / 4 "channels", same indexing as the other modes).
-enum ConvPrecision : int { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_F16X2 = 2, PREC_FP8 = 3 };
+// PREC_F16C ("fp16 main term + fp8 cross terms"): a*b = a_hi*b_hi + (a_hi*b_lo + a_lo*b_hi) with hi = f16_rn(v), lo = v - hi.
+// The main term runs on v_mfma_f32_16x16x32_f16 (exact products), the two cross terms — 2^-11 of the product, so 4 bits of
+// them are enough — on the block-scaled fp8 MFMA (K = 128: both cross terms of two taps per instruction, twice the bf16
+// rate): two MFMA-equivalents per product instead of bf16x3's three, per-product error ~2^-15.  A 32-channel chunk (128
+// bytes, the split-bf16 geometry) holds [32 x hi f16 | h8 ch 0-15 | l8 ch 0-15 | h8 ch 16-31 | l8 ch 16-31] with
+// h8 = e4m3(v), l8 = e4m3(lo * 2^11) for activations; weights store [.. | l8 | h8 | l8 | h8] with a power-of-two scale per
+// output channel and kind (ConvParams.wexp: byte 0 = e8m0 of the lo pieces, byte 1 = of the hi pieces).
+enum ConvPrecision : int { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_F16X2 = 2, PREC_FP8 = 3, PREC_F16C = 4 };
 
 __host__ __device__ inline unsigned msr_bf16_rn(float v) {   // round-to-nearest-even, finite inputs
     union { float f; unsigned u; } c;
@@ -149,6 +157,24 @@ inline unsigned char msr_f32_to_e4m3(float v) {
     return sign | (unsigned char)(((e + 7) << 3) | ((int)r - 8));
 }
 
+// Device: 4 consecutive channels c..c+3 (c % 4 == 0) of one pixel into the pixel's f16c chunk image (PREC_F16C above).
+__device__ inline void msr_store_f16c4_dev(float* pixel, int c, float v0, float v1, float v2, float v3) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 a = {(_Float16)v0, (_Float16)v1}, b = {(_Float16)v2, (_Float16)v3};
+    const float l0 = v0 - (float)a[0], l1 = v1 - (float)a[1], l2 = v2 - (float)b[0], l3 = v3 - (float)b[1];
+    unsigned* chunk = reinterpret_cast<unsigned*>(pixel) + (c & ~31);
+    const int cc = c & 31;
+    *reinterpret_cast<uint2*>(chunk + (cc >> 1)) = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+    unsigned h8 = 0, l8 = 0;
+    h8 = __builtin_amdgcn_cvt_pk_fp8_f32(v0, v1, h8, false);
+    h8 = __builtin_amdgcn_cvt_pk_fp8_f32(v2, v3, h8, true);
+    l8 = __builtin_amdgcn_cvt_pk_fp8_f32(l0 * 2048.f, l1 * 2048.f, l8, false);
+    l8 = __builtin_amdgcn_cvt_pk_fp8_f32(l2 * 2048.f, l3 * 2048.f, l8, true);
+    const int piece = 16 + 8 * (cc >> 4) + ((cc & 15) >> 2);        // dword of the h8 piece; the l8 piece is 4 dwords on
+    chunk[piece] = h8;
+    chunk[piece + 4] = l8;
+}
+
 enum ConvTile : int { TILE_128x128 = 0, TILE_64x64 = 1, TILE_128x128_K16 = 2, TILE_128x128_HALO = 3, TILE_128x128_HALO16 = 4, TILE_256x128_PP = 5 };
 
 hipError_t conv_igemm_init();   // sets dynamic-LDS attributes once
@@ -180,7 +206,7 @@ struct SmallCinParams {
     int act;            // 0 none, 1 relu, 2 leaky(slope)
     float slope;
     int out_split;      // 1: write split-bf16 words for a PREC_BF16X3 consumer; 2: split-fp16 words (PREC_F16X2);
-                        // 3: bf8 e5m2 bytes (PREC_FP8; one dword per 4 channels)
+                        // 3: bf8 e5m2 bytes (PREC_FP8; one dword per 4 channels); 4: the f16c chunk image (PREC_F16C)
 };
 hipError_t launch_conv_smallcin(const SmallCinParams& p, hipStream_t s);
 hipError_t launch_split_bf16(const float* in, float* out, long n, hipStream_t s);

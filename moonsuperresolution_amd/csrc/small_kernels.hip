@@ -76,7 +76,9 @@ __global__ void __launch_bounds__(256) conv_smallcin_kernel(const SmallCinParams
                 acc.x = acc.x >= 0.f ? acc.x : acc.x * p.slope; acc.y = acc.y >= 0.f ? acc.y : acc.y * p.slope;
                 acc.z = acc.z >= 0.f ? acc.z : acc.z * p.slope; acc.w = acc.w >= 0.f ? acc.w : acc.w * p.slope;
             }
-            if (p.out_split == 3) {
+            if (p.out_split == 4) {
+                msr_store_f16c4_dev(o + (size_t)i * p.out_px, q * 4, acc.x, acc.y, acc.z, acc.w);
+            } else if (p.out_split == 3) {
                 unsigned w8 = 0;
                 w8 = __builtin_amdgcn_cvt_pk_bf8_f32(acc.x, acc.y, w8, false);
                 w8 = __builtin_amdgcn_cvt_pk_bf8_f32(acc.z, acc.w, w8, true);

@@ -177,3 +177,77 @@ def conv3x3_fp8(ctx: OpContext, x_bytes: torch.Tensor, w_bytes: torch.Tensor, we
                                     1 if out_padded else 0, out_mode, torch.cuda.current_stream(x_bytes.device).cuda_stream)
     _lib.raise_for(ctx.lib, ctx.h, rc, "msr_op_conv3x3_fp8")
     return out
+
+
+def _f16c_pack(hi_f16: torch.Tensor, p_even: torch.Tensor, p_odd: torch.Tensor) -> torch.Tensor:
+    """[..., C] f16 + two [..., C] float8 tensors -> the 128-byte chunk image per 32 channels, as float32 storage [..., C]:
+    [32 x f16 | even piece ch 0-15 | odd piece ch 0-15 | even piece ch 16-31 | odd piece ch 16-31]."""
+    shp = hi_f16.shape
+    n = shp[-1] // 32
+    img = torch.empty(shp[:-1] + (n, 128), dtype=torch.uint8, device=hi_f16.device)
+    img[..., 0:64] = hi_f16.contiguous().view(torch.uint8).reshape(shp[:-1] + (n, 64))
+    e = p_even.contiguous().view(torch.uint8).reshape(shp[:-1] + (n, 32))
+    o = p_odd.contiguous().view(torch.uint8).reshape(shp[:-1] + (n, 32))
+    img[..., 64:80], img[..., 80:96] = e[..., 0:16], o[..., 0:16]
+    img[..., 96:112], img[..., 112:128] = e[..., 16:32], o[..., 16:32]
+    return img.reshape(shp[:-1] + (n * 128,)).view(torch.float32).reshape(shp)
+
+
+def f16c_activation_image(x: torch.Tensor):
+    """fp32 [..., C] (C % 32 == 0) -> (f16c chunk image as float32 storage, (hi, h8, lo8) de-quantised float64 parts):
+    hi = f16_rn(v), h8 = e4m3(v), lo8 = e4m3((v - hi) * 2^11) / 2^11 — what the SPADE epilogue / mask embedding write."""
+    hi = x.to(torch.float16)
+    lo = x - hi.float()
+    h8 = x.clamp(-448, 448).to(torch.float8_e4m3fn)
+    l8 = (lo * 2048.0).clamp(-448, 448).to(torch.float8_e4m3fn)
+    return _f16c_pack(hi, h8, l8), (hi.double(), h8.double(), l8.double() / 2048.0)
+
+
+def f16c_weight_image(w_kl: torch.Tensor):
+    """Kernel-layout weights [taps][N][Cin] -> (f16c image, wexp int32 [N], (hi, h8, lo8) de-quantised): pieces are stored
+    lo-first so that piece g of a weight row pairs with piece g of an activation row (w_lo * x_hi, w_hi * x_lo)."""
+    hi = w_kl.to(torch.float16)
+    lo = w_kl - hi.float()
+
+    def pow2exp(t):
+        amax = t.abs().amax(dim=(0, 2)).float().cpu()
+        e = torch.zeros(amax.shape, dtype=torch.int64)
+        nz = amax > 0
+        e[nz] = torch.frexp(amax[nz] / 448.0)[1].to(torch.int64)
+        return e
+    eh, el = pow2exp(w_kl), pow2exp(lo)
+    sh = torch.pow(2.0, eh.double()).float().to(w_kl.device)[None, :, None]
+    sl = torch.pow(2.0, el.double()).float().to(w_kl.device)[None, :, None]
+    h8 = (w_kl / sh).to(torch.float8_e4m3fn)
+    l8 = (lo / sl).to(torch.float8_e4m3fn)
+    wexp = ((127 + el) | ((127 + eh) << 8)).to(torch.int32).to(w_kl.device)
+    return _f16c_pack(hi, l8, h8), wexp.contiguous(), (hi.double(), h8.double() * sh.double(), l8.double() * sl.double())
+
+
+def conv3x3_f16c(ctx: OpContext, x_img: torch.Tensor, w_img: torch.Tensor, wexp: torch.Tensor, bias: torch.Tensor, rout: int,
+                 epilogue: int = EPI_BIAS, aux: Optional[torch.Tensor] = None, aux_shift: int = 0,
+                 mean: Optional[torch.Tensor] = None, std: Optional[torch.Tensor] = None, out_padded: bool = False,
+                 out_mode: int = 0) -> torch.Tensor:
+    """One launch of the f16c form of the persistent ping-pong conv (msr_op_conv3x3_f16c)."""
+    B, Cin = x_img.shape[0], x_img.shape[3]
+    N = w_img.shape[1]
+    Cout = N // 2 if epilogue == EPI_SPADE else N
+    shape = (B, rout + 2, rout + 2, Cout) if out_padded else (B, rout, rout, Cout)
+    out = torch.zeros(shape, dtype=torch.float32, device=x_img.device)
+    p = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+    rc = ctx.lib.msr_op_conv3x3_f16c(ctx.h, x_img.data_ptr(), w_img.data_ptr(), wexp.data_ptr(), bias.data_ptr(),
+                                     out.data_ptr(), B, rout, Cin, N, epilogue, p(aux), aux_shift, p(mean), p(std),
+                                     1 if out_padded else 0, out_mode, torch.cuda.current_stream(x_img.device).cuda_stream)
+    _lib.raise_for(ctx.lib, ctx.h, rc, "msr_op_conv3x3_f16c")
+    return out
+
+
+def f16c_decode(img: torch.Tensor):
+    """f16c activation image (float32 storage [..., C]) -> (hi, h8, lo8) as float64 tensors [..., C]."""
+    shp = img.shape
+    n = shp[-1] // 32
+    b = img.contiguous().view(torch.uint8).reshape(shp[:-1] + (n, 128))
+    hi = b[..., 0:64].contiguous().view(torch.float16).reshape(shp).double()
+    h8 = torch.cat([b[..., 64:80], b[..., 96:112]], dim=-1).contiguous().view(torch.float8_e4m3fn).reshape(shp).double()
+    l8 = torch.cat([b[..., 80:96], b[..., 112:128]], dim=-1).contiguous().view(torch.float8_e4m3fn).reshape(shp).double()
+    return hi, h8, l8 / 2048.0

@@ -70,7 +70,7 @@ def _record(**kw):
     print("parity", kw)
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "fp32", "bf16x3_gbf16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32", "bf16x3_gbf16", "f16c"])
 @pytest.mark.parametrize("S,B", [(256, 16), (512, 8), (512, 12)])
 def test_baseline_config_matches_oracle(hip_lib, S, B, precision):
     from moonsuperresolution_amd import Generator

@@ -294,3 +294,65 @@ def test_conv_fp8_spade_epilogue_bf8_output(ctx):
     ulp = torch.maximum(want.abs() * 0.25, torch.tensor(2.0 ** -16))               # one bf8 step (2 mantissa bits; subnormal floor)
     assert bool(((got - want).abs() <= ulp * 1.001)[mism].all())
     assert int(y8[:, 0].max()) == 0 and int(y8[:, :, -1].max()) == 0     # the border stays zero
+
+
+def _ref_f16c(xparts, wparts, bias, cin, cout):
+    """What the f16c kernel computes, in float64: x_hi*w_hi + x_h8*w_lo8 + x_lo8*w_h8 (+ bias)."""
+    (xh, x8, xl), (wh, w8, wl) = xparts, wparts
+    hwio = lambda t: t.permute(0, 2, 1).reshape(3, 3, cin, cout)   # noqa: E731
+    zero = torch.zeros(cout, dtype=torch.float64)
+    return (ref_conv(xh, hwio(wh), bias, 1) + ref_conv(x8, hwio(wl), zero, 1) + ref_conv(xl, hwio(w8), zero, 1))
+
+
+@pytest.mark.parametrize("B,r,cin,cout", [(2, 16, 64, 128), (1, 32, 256, 256), (3, 64, 128, 128), (9, 32, 128, 512)])
+def test_conv_f16c(ctx, B, r, cin, cout):
+    """fp16 main term + fp8 cross terms (MSR_FLAG_F16C): against the float64 evaluation of exactly those three terms on the
+    de-quantised operands the kernel is exact up to accumulation (<= 5e-5: pins the chunk image, the pairing of the
+    pieces of two taps in one 128-deep MFMA and the per-lane scales); against the float64 conv of the ORIGINAL operands it
+    holds 2e-4 at kernel level (per-product error ~2^-15; weights spanning three decades)."""
+    from moonsuperresolution_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(51 + B + r)
+    x = torch.randn((B, r, r, cin), generator=g).cuda()
+    w = (torch.randn((3, 3, cin, cout), generator=g) / np.sqrt(9 * cin) * torch.logspace(-2, 1, cout)).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    ximg, xparts = ops.f16c_activation_image(ops.pad_nhwc(x))
+    wimg, wexp, wparts = ops.f16c_weight_image(ops.kernel_layout(w))
+    y = ops.conv3x3_f16c(ctx, ximg, wimg, wexp, b, r).cpu().numpy()
+    xin = tuple(t[:, 1:-1, 1:-1].cpu() for t in xparts)
+    emu = _ref_f16c(xin, tuple(t.cpu() for t in wparts), b, cin, cout).numpy()
+    e_emu, e_true = rel_linf(y, emu), rel_linf(y, ref_conv(x, w, b, 1).numpy())
+    print("f16c conv: vs its own three terms in fp64", e_emu, " vs the fp64 conv", e_true)
+    assert e_emu <= 5e-5, e_emu
+    assert e_true <= 2e-4, e_true
+
+
+def test_conv_f16c_spade_epilogue_writes_the_chunk_image(ctx):
+    from moonsuperresolution_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(53)
+    B, r, C, shift = 3, 32, 128, 1
+    h = torch.relu(torch.randn((B, r, r, 128), generator=g)).cuda()
+    wg = (torch.randn((3, 3, 128, C), generator=g) / 34).cuda()
+    wb_ = (torch.randn((3, 3, 128, C), generator=g) / 34).cuda()
+    bg, bb = torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+    x = (3 + 2 * torch.randn((B, r >> shift, r >> shift, C), generator=g)).cuda()
+    mean = x.mean((0, 1, 2)).contiguous()
+    std = torch.sqrt(x.var((0, 1, 2), unbiased=False) + 1e-5).contiguous()
+    w, bias = ops.spade_layout(wg, wb_, bg, bb)
+    himg, _ = ops.f16c_activation_image(ops.pad_nhwc(h))
+    wimg, wexp, _ = ops.f16c_weight_image(w)
+    xr = x.double().cpu().repeat_interleave(2, 1).repeat_interleave(2, 2)
+    v = ref_conv(h, wg, bg, 1) * ((xr - mean.double().cpu()) / std.double().cpu()) + ref_conv(h, wb_, bb, 1)
+    v = torch.where(v >= 0, v, 0.2 * v)
+    y32 = ops.conv3x3_f16c(ctx, himg, wimg, wexp, bias, r, epilogue=ops.EPI_SPADE, aux=x, aux_shift=shift, mean=mean, std=std,
+                           out_padded=True, out_mode=0)
+    assert rel_linf(y32.cpu()[:, 1:-1, 1:-1].numpy(), v.numpy()) <= 2e-4
+    yc = ops.conv3x3_f16c(ctx, himg, wimg, wexp, bias, r, epilogue=ops.EPI_SPADE, aux=x, aux_shift=shift, mean=mean, std=std,
+                          out_padded=True, out_mode=4)
+    hi, h8, lo8 = (t.cpu()[:, 1:-1, 1:-1] for t in ops.f16c_decode(yc))
+    want = y32.cpu()[:, 1:-1, 1:-1].double()
+    scale = float(want.abs().max())
+    assert float((hi - want).abs().max()) <= 2.0 ** -11 * scale                 # hi is the fp16 rounding of the value
+    assert float((hi + lo8 - want).abs().max()) <= 2.0 ** -14 * scale           # hi + lo8 recovers ~15 bits
+    assert float(((h8 - want).abs() / want.abs().clamp_min(2.0 ** -6)).max()) <= 2.0 ** -4 * 1.01   # h8 = e4m3 of the value
+    full = ops.f16c_decode(yc)
+    assert float(full[0][:, 0].abs().max()) == 0 and float(full[1][:, :, -1].abs().max()) == 0     # the border stays zero
