@@ -317,8 +317,8 @@ bool main_uses_f16c(msr_handle* h, int rout, int cin, int cout) {
     return h->f16c && cin % 64 == 0 && conv_fills_pp(h->B, rout, cout) && conv_fills_pp(h->B, rout, 2 * cin);
 }
 
-// f16c image of [taps][N][Cin] weights (kernels.h PREC_F16C): per 32-channel chunk [32 x hi f16 | l8 ch 0-15 | h8 ch 0-15 |
-// l8 ch 16-31 | h8 ch 16-31] with hi = f16_rn(w), l8 = e4m3((w - hi) * 2^-el), h8 = e4m3(w * 2^-eh), el / eh powers of two
+// f16c image of [taps][N][Cin] weights (kernels.h PREC_F16C): per 32-channel chunk [32 x hi f16 | 32 x l8 | 32 x h8]
+// with hi = f16_rn(w), l8 = e4m3((w - hi) * 2^-el), h8 = e4m3(w * 2^-eh), el / eh powers of two
 // per output channel; key + ".wexp"[n] = (127 + el) | (127 + eh) << 8
 int upload_conv_weight_f16c(msr_handle* h, const std::string& key, const float* host, int taps, int N, int Cin) {
     if (Cin % 32) return fail(h, MSR_ERR_INVALID, "%s: f16c needs Cin %% 32 == 0", key.c_str());
@@ -349,9 +349,8 @@ int upload_conv_weight_f16c(msr_handle* h, const std::string& key, const float* 
                     const float w = host[((size_t)t * N + n) * Cin + c0 + c];
                     const _Float16 hi = (_Float16)w;
                     reinterpret_cast<_Float16*>(chunk)[c] = hi;
-                    unsigned char* piece = chunk + 64 + 32 * (c >> 4) + (c & 15);     // l8 piece, h8 piece 16 bytes on
-                    piece[0] = msr_f32_to_e4m3((w - (float)hi) * il);
-                    piece[16] = msr_f32_to_e4m3(w * ih);
+                    chunk[64 + c] = msr_f32_to_e4m3((w - (float)hi) * il);
+                    chunk[96 + c] = msr_f32_to_e4m3(w * ih);
                 }
             }
     }

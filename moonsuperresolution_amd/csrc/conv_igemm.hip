@@ -1111,13 +1111,15 @@ conv_igemm_bf16x3_halo(const ConvParams p, const TileGeom g) {
 // instead of 48 and 16.
 // MODE 2 (PP_FP8) is the declared non-parity fp8 form (kernels.h PREC_FP8): a chunk row holds 128 one-byte channels,
 // a K-step is 128 channels of one tap: 16 block-scaled MFMAs (K = 128 each), same staging and fragment reads.
-// MODE 3 (PP_F16C, kernels.h PREC_F16C): fp16 main term + fp8 cross terms.  A chunk row holds [32 x hi f16 | four 16-byte
-// pieces: h8 ch 0-15, l8 ch 0-15, h8 ch 16-31, l8 ch 16-31] (weights: l8 / h8 swapped so that piece g of one pairs with
-// piece g of the other: w_lo*x_hi, w_hi*x_lo).  Every K-step runs the 16 f16 MFMAs of its tap (x_hi * w_hi); the lane's
-// piece (16 bytes at +64 + 16 * (lane >> 4): the same conflict-free read as the bf16 lo half) of an EVEN step and of the
-// following ODD step make one 32-byte operand, and the odd step adds 16 block-scaled K = 128 fp8 MFMAs that cover the
-// cross terms of both taps, each lane's e8m0 scale selecting its piece's scale (hi or lo).  Two MFMA-equivalents per
-// product instead of three; per-product error ~2^-15 (the fp8 rounding of a term that is 2^-11 of the product).
+// MODE 3 (PP_F16C, kernels.h PREC_F16C): fp16 main term + fp8 cross terms.  A chunk row holds [32 x hi f16 | 32 x h8 |
+// 32 x l8] (weights: l8 then h8, so that byte t of one pairs with byte t of the other: w_lo*x_hi, w_hi*x_lo).  Every
+// K-step runs the 16 f16 MFMAs of its tap (x_hi * w_hi); the lane's 16 bytes at +64 + 16 * (lane >> 4) (the same
+// conflict-free read as the bf16 lo half) of an EVEN step and of the following ODD step make one 32-byte operand, and the
+// odd step adds 16 block-scaled K = 128 fp8 MFMAs that cover the cross terms of both taps.  In that instruction a lane's
+// first 16 bytes are k = 16g.. of the first 64 and its second 16 bytes of the second 64, and k-block b takes its e8m0
+// scale from lane group b: blocks 0 / 2 are the even / odd tap's h8 (w: l8) bytes, blocks 1 / 3 their l8 (w: h8) bytes,
+// so lane groups 0, 2 carry the scale of the first kind and 1, 3 of the second.  Two MFMA-equivalents per product
+// instead of three; per-product error ~2^-15 (the fp8 rounding of a term that is 2^-11 of the product).
 enum PpMode : int { PP_BF16X3 = 0, PP_F16X2 = 1, PP_FP8 = 2, PP_F16C = 3 };
 // ONE = true: the input has ONE 32-slot chunk (the Cin = 128 convs of the fp8 mode: 128 one-byte channels).  The
 // unrolled body of 18 K-steps then covers TWO work items (tiles) of 9 taps each instead of a chunk pair of one tile:

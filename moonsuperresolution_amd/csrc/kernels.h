@@ -76,9 +76,11 @@ struct ConvParams {
 // The main term runs on v_mfma_f32_16x16x32_f16 (exact products), the two cross terms — 2^-11 of the product, so 4 bits of
 // them are enough — on the block-scaled fp8 MFMA (K = 128: both cross terms of two taps per instruction, twice the bf16
 // rate): two MFMA-equivalents per product instead of bf16x3's three, per-product error ~2^-15.  A 32-channel chunk (128
-// bytes, the split-bf16 geometry) holds [32 x hi f16 | h8 ch 0-15 | l8 ch 0-15 | h8 ch 16-31 | l8 ch 16-31] with
-// h8 = e4m3(v), l8 = e4m3(lo * 2^11) for activations; weights store [.. | l8 | h8 | l8 | h8] with a power-of-two scale per
-// output channel and kind (ConvParams.wexp: byte 0 = e8m0 of the lo pieces, byte 1 = of the hi pieces).
+// bytes, the split-bf16 geometry) holds [32 x hi f16 | 32 x h8 | 32 x l8] with h8 = e4m3(v), l8 = e4m3(lo * 2^11) for
+// activations; weights store [32 x hi f16 | 32 x l8 | 32 x h8] (so that byte t of one pairs with byte t of the other:
+// w_lo * x_hi, w_hi * x_lo) with a power-of-two scale per output channel and kind (ConvParams.wexp: byte 0 = e8m0 of the
+// lo bytes, byte 1 = of the hi bytes).  Operand map of v_mfma_scale_f32_16x16x128_f8f6f4 as measured: lane (row, g)'s 32
+// bytes are k = 16g..16g+15 and 64+16g..64+16g+15; the e8m0 scale of k-block b (32 consecutive k) comes from lane group b.
 enum ConvPrecision : int { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_F16X2 = 2, PREC_FP8 = 3, PREC_F16C = 4 };
 
 __host__ __device__ inline unsigned msr_bf16_rn(float v) {   // round-to-nearest-even, finite inputs
@@ -170,9 +172,8 @@ __device__ inline void msr_store_f16c4_dev(float* pixel, int c, float v0, float 
     h8 = __builtin_amdgcn_cvt_pk_fp8_f32(v2, v3, h8, true);
     l8 = __builtin_amdgcn_cvt_pk_fp8_f32(l0 * 2048.f, l1 * 2048.f, l8, false);
     l8 = __builtin_amdgcn_cvt_pk_fp8_f32(l2 * 2048.f, l3 * 2048.f, l8, true);
-    const int piece = 16 + 8 * (cc >> 4) + ((cc & 15) >> 2);        // dword of the h8 piece; the l8 piece is 4 dwords on
-    chunk[piece] = h8;
-    chunk[piece + 4] = l8;
+    chunk[16 + (cc >> 2)] = h8;                                    // bytes 64..95: h8 of the 32 channels
+    chunk[24 + (cc >> 2)] = l8;                                    // bytes 96..127: l8
 }
 
 enum ConvTile : int { TILE_128x128 = 0, TILE_64x64 = 1, TILE_128x128_K16 = 2, TILE_128x128_HALO = 3, TILE_128x128_HALO16 = 4, TILE_256x128_PP = 5 };

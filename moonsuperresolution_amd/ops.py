@@ -181,15 +181,14 @@ def conv3x3_fp8(ctx: OpContext, x_bytes: torch.Tensor, w_bytes: torch.Tensor, we
 
 def _f16c_pack(hi_f16: torch.Tensor, p_even: torch.Tensor, p_odd: torch.Tensor) -> torch.Tensor:
     """[..., C] f16 + two [..., C] float8 tensors -> the 128-byte chunk image per 32 channels, as float32 storage [..., C]:
-    [32 x f16 | even piece ch 0-15 | odd piece ch 0-15 | even piece ch 16-31 | odd piece ch 16-31]."""
+    [32 x f16 | 32 bytes of the first float8 tensor | 32 bytes of the second]."""
     shp = hi_f16.shape
     n = shp[-1] // 32
     img = torch.empty(shp[:-1] + (n, 128), dtype=torch.uint8, device=hi_f16.device)
     img[..., 0:64] = hi_f16.contiguous().view(torch.uint8).reshape(shp[:-1] + (n, 64))
     e = p_even.contiguous().view(torch.uint8).reshape(shp[:-1] + (n, 32))
     o = p_odd.contiguous().view(torch.uint8).reshape(shp[:-1] + (n, 32))
-    img[..., 64:80], img[..., 80:96] = e[..., 0:16], o[..., 0:16]
-    img[..., 96:112], img[..., 112:128] = e[..., 16:32], o[..., 16:32]
+    img[..., 64:96], img[..., 96:128] = e, o
     return img.reshape(shp[:-1] + (n * 128,)).view(torch.float32).reshape(shp)
 
 
@@ -248,6 +247,6 @@ def f16c_decode(img: torch.Tensor):
     n = shp[-1] // 32
     b = img.contiguous().view(torch.uint8).reshape(shp[:-1] + (n, 128))
     hi = b[..., 0:64].contiguous().view(torch.float16).reshape(shp).double()
-    h8 = torch.cat([b[..., 64:80], b[..., 96:112]], dim=-1).contiguous().view(torch.float8_e4m3fn).reshape(shp).double()
-    l8 = torch.cat([b[..., 80:96], b[..., 112:128]], dim=-1).contiguous().view(torch.float8_e4m3fn).reshape(shp).double()
+    h8 = b[..., 64:96].contiguous().view(torch.float8_e4m3fn).reshape(shp).double()
+    l8 = b[..., 96:128].contiguous().view(torch.float8_e4m3fn).reshape(shp).double()
     return hi, h8, l8 / 2048.0
