@@ -10,13 +10,15 @@ over one batch of synthetic (ortho, low-res DEM) patches that is already residen
     spade256 (configs[1]): GauGAN(256, 16, 256), batch [16,256,256,2] = 4 tiles of 512x512 per step
 Metric: 512x512 DEM tiles/s over the whole job (a 512x512 tile = four 256x256 patches).
 
-Conv arithmetic (--precision): "bf16x3" (default) = 3-term split-bf16 products on v_mfma_f32_16x16x32_bf16 with fp32
-accumulation, inputs / outputs / weights / all other ops fp32 — ~2e-5 relative L-inf vs the float64 oracle, inside the
-1e-3 bar of BASELINE.json (tests/test_gpu_baseline_configs.py runs these very shapes); "fp32" = exact fp32 MFMA.
+Conv arithmetic (--precision; inputs / outputs / weights / accumulation / all other ops fp32 in every mode):
+"f16c" (default) = fp16 main term on v_mfma_f32_16x16x32_f16 + both cross terms on the block-scaled fp8 MFMA in the convs
+that fill the chip (two MFMA-equivalents per product), 3-term split-bf16 elsewhere — 3.6-4.7e-5 relative L-inf vs the
+oracle on these very shapes (tests/test_gpu_baseline_configs.py), inside the 1e-3 bar of BASELINE.json; "bf16x3" = 3-term
+split-bf16 everywhere (1.7-2.0e-5); "fp32" = exact fp32 MFMA; "bf16x3_gbf16" opt-in; "fp8" declared non-parity.
 
-At N = 1 the one JSON line also carries, under "also", the driver-timed figures of the other single-GPU
-configurations (spade256 in bf16x3 and in fp32: value, ms_per_step, roofline each, same K and W), the B = 1
-single-call latency ("p50_ms_per_call_b1"), and the CPU baseline.
+At N = 1 the one JSON line also carries, under "also", the driver-timed figures of the other modes and of the other
+single-GPU configuration (spade512 in bf16x3 / bf16x3_gbf16 / fp8, spade256 in f16c / bf16x3 / fp32: value, ms_per_step,
+roofline each, same K and W), the B = 1 single-call latency ("p50_ms_per_call_b1"), and the CPU baseline.
 
 N > 1: `python bench.py --gpus N` launches its own N workers (fresh child processes of torch.distributed.run, before
 this process touches HIP); under an outer `python -m torch.distributed.run ... bench.py --gpus N` (WORLD_SIZE set) it
@@ -319,7 +321,9 @@ def run_workload(args, D: Dist, workload: str, precision: str, with_cpu: bool, w
             rl["note"] = (f"frac = algorithmic FLOP/s over the dense bf16/f16 MFMA peak; {precision} issues {k} MFMA "
                           "products per algorithmic product (average over the conv FLOPs), so the matrix pipe executes "
                           "that multiple of `achieved` (frac_of_executed_mfma_peak) and frac is capped at 1/" + str(k))
-        pmc = pmc_traffic(workload + ("" if precision == "fp32" else "_bf16x3"))
+        # the modes that keep the split-bf16 tensor geometry move the same bytes: fall back to the bf16x3 passes
+        pmc = pmc_traffic(workload + ("" if precision == "fp32" else "_" + precision)) or (
+            pmc_traffic(workload + "_bf16x3") if precision in ("f16c", "bf16x3_gbf16") else None)
         if pmc and "conv_igemm" in pmc[0]:
             rl["traffic"] = pmc[0]["conv_igemm"]["hbm_bytes_per_forward"] / (conv["launches"] / args.steps)
             rl["traffic_source"] = "profiles/" + pmc[1]
@@ -379,8 +383,10 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="spade512")
-    ap.add_argument("--precision", choices=sorted(PEAK_TFLOPS), default="bf16x3",
-                    help="conv arithmetic: exact fp32 MFMA, or 3-term split-bf16 on the bf16 MFMA (fp32 accumulate)")
+    ap.add_argument("--precision", choices=sorted(PEAK_TFLOPS), default="f16c",
+                    help="conv arithmetic (fp32 accumulation in every mode): f16c = fp16 main term + fp8 cross terms (default, "
+                         "parity), bf16x3 = 3-term split-bf16 (parity), fp32 = exact fp32 MFMA (parity), bf16x3_gbf16 = opt-in "
+                         "2-term gamma|beta convs, fp8 = declared non-parity")
     ap.add_argument("--streams", type=int, default=1, help="generator handles / HIP streams the steps alternate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the other single-GPU configurations and the B=1 latency")
@@ -398,8 +404,8 @@ def main():
                        with_b1=solo and not args.no_also)
     if solo and not args.no_also:
         also = {}
-        for wl, prec in (("spade512", "f16c"), ("spade512", "bf16x3_gbf16"), ("spade512", "fp8"), ("spade256", "bf16x3"),
-                         ("spade256", "fp32")):
+        for wl, prec in (("spade512", "bf16x3"), ("spade512", "bf16x3_gbf16"), ("spade512", "fp8"), ("spade256", "f16c"),
+                         ("spade256", "bf16x3"), ("spade256", "fp32")):
             if (wl, prec) == (args.workload, args.precision):
                 continue
             r = run_workload(args, D, wl, prec, with_cpu=False, with_b1=False)

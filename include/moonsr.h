@@ -56,7 +56,7 @@ typedef struct {
 /* Conv arithmetic (msr_config.flags).  Inputs, outputs and weights of the C ABI are fp32 in every mode, and so is all
  * other arithmetic (moments, normalisation, epilogues, dense layers, head); only the conv products differ:
  *   0                 exact fp32 on v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak).  NOTE: 0 is the C-ABI default; the Python
- *                     host (moonsuperresolution_amd.Generator) defaults to MSR_FLAG_BF16X3, which is ~3.4x faster.
+ *                     host (moonsuperresolution_amd.Generator) defaults to MSR_FLAG_BF16X3 | MSR_FLAG_F16C, ~4x faster.
  *   MSR_FLAG_BF16X3   3-term split-bf16 products (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi) with fp32 accumulation, on
  *                     v_mfma_f32_16x16x32_bf16 in the LDS-halo kernels (the r >= 16 layers, 91 % of the FLOPs) and on
  *                     v_mfma_f32_32x32x16_bf16 in the small-tile ones: per-product error <= ~3*2^-18.

@@ -162,6 +162,12 @@ inline unsigned char msr_f32_to_e4m3(float v) {
 // Device: 4 consecutive channels c..c+3 (c % 4 == 0) of one pixel into the pixel's f16c chunk image (PREC_F16C above).
 __device__ inline void msr_store_f16c4_dev(float* pixel, int c, float v0, float v1, float v2, float v3) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    // fp16's range, not fp32's: a value beyond 65504 saturates (finite, wrong) instead of turning the conv into infinities;
+    // NaN passes through (fminf / fmaxf would drop it, the ternaries keep it)
+    v0 = v0 > 65504.f ? 65504.f : (v0 < -65504.f ? -65504.f : v0);
+    v1 = v1 > 65504.f ? 65504.f : (v1 < -65504.f ? -65504.f : v1);
+    v2 = v2 > 65504.f ? 65504.f : (v2 < -65504.f ? -65504.f : v2);
+    v3 = v3 > 65504.f ? 65504.f : (v3 < -65504.f ? -65504.f : v3);
     const h2 a = {(_Float16)v0, (_Float16)v1}, b = {(_Float16)v2, (_Float16)v3};
     const float l0 = v0 - (float)a[0], l1 = v1 - (float)a[1], l2 = v2 - (float)b[0], l3 = v3 - (float)b[1];
     unsigned* chunk = reinterpret_cast<unsigned*>(pixel) + (c & ~31);

@@ -5,7 +5,7 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/collect_r02; mkdir -p $O
 # per-layer tables (known call count, one stream, launches in plan order)
-for cfg in "spade512 bf16x3" "spade512 bf16x3_gbf16" "spade512 fp8" "spade256 bf16x3"; do
+for cfg in "spade512 f16c" "spade512 bf16x3" "spade512 bf16x3_gbf16" "spade512 fp8" "spade256 f16c" "spade256 bf16x3"; do
   set -- $cfg; wl=$1; pr=$2; S=${wl#spade}; B=16; [ $S = 512 ] && B=8
   rocprofv3 --kernel-trace --stats -d $O/kt_${wl}_$pr -o kt --output-format csv -- python3 profiles/run_forwards.py $wl 25 $pr > $O/kt_${wl}_$pr.log 2>&1 || exit 1
   python profiles/analyze_trace.py $O/kt_${wl}_$pr/kt_kernel_trace.csv $S $B > $O/${wl}_${pr}_conv_layers.txt || exit 1
@@ -14,12 +14,16 @@ for cfg in "spade512 bf16x3" "spade512 bf16x3_gbf16" "spade512 fp8" "spade256 bf
 done
 # HBM traffic of the default workload: separate PMC passes
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $O/pmc_$c -o p --output-format csv -- python3 profiles/run_forwards.py spade512 3 > $O/pmc_$c.log 2>&1 || exit 1
+  rocprofv3 --pmc $c --kernel-trace -d $O/pmc_$c -o p --output-format csv -- python3 profiles/run_forwards.py spade512 3 f16c > $O/pmc_$c.log 2>&1 || exit 1
+  rocprofv3 --pmc $c --kernel-trace -d $O/pmc_bf_$c -o p --output-format csv -- python3 profiles/run_forwards.py spade512 3 bf16x3 > $O/pmc_bf_$c.log 2>&1 || exit 1
 done
-python profiles/summarize_pmc.py $O/pmc_FETCH_SIZE/p_counter_collection.csv $O/pmc_WRITE_SIZE/p_counter_collection.csv spade512_bf16x3 $O/spade512_bf16x3_pmc_summary.json 3 > /dev/null || exit 1
+python profiles/summarize_pmc.py $O/pmc_FETCH_SIZE/p_counter_collection.csv $O/pmc_WRITE_SIZE/p_counter_collection.csv spade512_f16c $O/spade512_f16c_pmc_summary.json 3 > /dev/null || exit 1
+python profiles/summarize_pmc.py $O/pmc_bf_FETCH_SIZE/p_counter_collection.csv $O/pmc_bf_WRITE_SIZE/p_counter_collection.csv spade512_bf16x3 $O/spade512_bf16x3_pmc_summary.json 3 > /dev/null || exit 1
 echo "pmc traffic done"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d $O/pmc_sq -o p --output-format csv -- python3 profiles/run_forwards.py spade512 3 > $O/pmc_sq.log 2>&1 || exit 1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d $O/pmc_sq -o p --output-format csv -- python3 profiles/run_forwards.py spade512 3 bf16x3 > $O/pmc_sq.log 2>&1 || exit 1
 python profiles/pmc_util.py $O/pmc_sq/p_counter_collection.csv conv > $O/spade512_bf16x3_sq_counters.txt || exit 1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d $O/pmc_sq_f16c -o p --output-format csv -- python3 profiles/run_forwards.py spade512 3 f16c > $O/pmc_sq_f16c.log 2>&1 || exit 1
+python profiles/pmc_util.py $O/pmc_sq_f16c/p_counter_collection.csv conv > $O/spade512_f16c_sq_counters.txt || exit 1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d $O/pmc_sq_gb -o p --output-format csv -- python3 profiles/run_forwards.py spade512 3 bf16x3_gbf16 > $O/pmc_sq_gb.log 2>&1 || exit 1
 python profiles/pmc_util.py $O/pmc_sq_gb/p_counter_collection.csv conv > $O/spade512_bf16x3_gbf16_sq_counters.txt || exit 1
 echo "pmc sq done"

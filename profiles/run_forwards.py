@@ -10,7 +10,7 @@ import torch
 from moonsuperresolution_amd import Generator, make_latent_noise, make_weights, synthetic_patches
 
 wl, n = sys.argv[1], int(sys.argv[2])
-prec = sys.argv[3] if len(sys.argv) > 3 else "bf16x3"
+prec = sys.argv[3] if len(sys.argv) > 3 else "f16c"
 S, B = (256, 16) if wl == "spade256" else (512, 8)
 gen = Generator(S, B, variant="gaugan", weights=make_weights("gaugan", S, seed=1234), eps=make_latent_noise(B, 256, 7),
                 precision=prec)

@@ -70,7 +70,7 @@ def main():
                     help="patch-row-sharded mode (halo.py): every patch position generated once, neighbour exchange of "
                          "the boundary-zone accumulators over send / recv; NOT reference-identical (see halo.py)")
     ap.add_argument("--passes", type=int, default=1, help="run the shard this many times; the last pass is reported")
-    ap.add_argument("--precision", default="bf16x3")
+    ap.add_argument("--precision", default="f16c")
     ap.add_argument("--pipeline", type=int, default=2)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
