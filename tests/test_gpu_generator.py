@@ -268,7 +268,7 @@ def test_bf16x3_precision_within_tolerance(Generator):
     assert err <= TOL
     gen.close()
     with pytest.raises(ValueError):
-        Generator(64, 2, precision="fp8")
+        Generator(64, 2, precision="int4")              # not one of fp32 / bf16x3 / f16c / bf16x3_gbf16 / fp8
 
 
 def test_load_GAN_model_from_savedmodel_dirs(Generator, tmp_path):
