@@ -93,8 +93,6 @@ struct msr_handle {
     int graph_on = 0;
     std::vector<GraphEntry> graphs;
     int gate_op = -1;                            // index of the first op of the matrix-bound part (msr_forward_gated)
-    int aux_late_op = -1;                        // main-stream op before which the second group of mask embeddings is forked
-    hipEvent_t ev_fork2 = nullptr;
     // profiling
     int prof_on = 0;                               // 0 off, 1 every launch, 2 runs of conv launches only
     std::vector<ProfRec> prof;
@@ -518,7 +516,6 @@ int msr_destroy(msr_handle* h) {
     for (auto& op : h->ops)
         if (op.done) hipEventDestroy(op.done);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
-    if (h->ev_fork2) hipEventDestroy(h->ev_fork2);
     if (h->aux) hipStreamDestroy(h->aux);
     delete h;
     return MSR_OK;
@@ -1176,7 +1173,6 @@ int ensure_plan(msr_handle* h) {
     if (!h->aux) {
         HIPCHK(h, hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming));
         // First use now: HIP binds a stream to a hardware queue when it is first used, in order, and queues whose ids
         // are equal modulo 4 share a dispatch pipe (profiles/r02_raster_queue_pairing.txt).  Callers that pipeline two
         // handles plan them back to back (Generator.prepare) so that their four busy streams land on four pipes.
@@ -1189,17 +1185,6 @@ int ensure_plan(msr_handle* h) {
     if (rc) return rc;
     h->fwd_flops = 0;
     h->gate_op = -1;
-    h->aux_late_op = -1;
-    {
-        static const bool late = !(std::getenv("MSR_AUX_LATE") && std::atoi(std::getenv("MSR_AUX_LATE")) == 0);
-        int spade_convs = 0;
-        if (late && h->variant != MSR_PIX2PIX)
-            for (size_t k = 0; k < h->ops.size(); ++k)
-                if (h->ops[k].type == OP_CONV && h->ops[k].epi == EPI_SPADE && ++spade_convs == 3) {   // rb1 has two SPADE layers
-                    h->aux_late_op = (int)k;
-                    break;
-                }
-    }
     for (size_t k = 0; k < h->ops.size(); ++k)
         if (h->ops[k].type == OP_CONV && h->ops[k].tile == TILE_256x128_PP && h->ops[k].conv.ksplit == 1) {
             h->gate_op = (int)k;     // first layer that fills the chip with persistent ping-pong tiles
@@ -1249,7 +1234,6 @@ int launch_all(msr_handle* h, const float* in_dev, const float* eps_dev, float* 
             HIPCHK(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
             for (auto& op : h->ops) {
                 if (!op.on_aux) continue;
-                if (h->aux_late_op >= 0 && op.aux_group == 1) continue;     // forked later (below)
                 SmallCinParams p = op.sc;
                 p.src = in_dev;
                 hipError_t e = launch_conv_smallcin(p, h->aux);
@@ -1273,21 +1257,6 @@ int launch_all(msr_handle* h, const float* in_dev, const float* eps_dev, float* 
     for (auto& op : h->ops) {
         ++op_index;
         if (use_aux && op.on_aux) continue;
-        if (use_aux && op_index == h->aux_late_op) {
-            // The mask embeddings of the high-resolution blocks (group 1: ~1 GB of writes at SPADE-512) are forked here,
-            // after the latency-bound start of the call (encoder, dense layers, rb1), instead of beside it: they then
-            // fill the tails of the chip-filling convs of rb2-rb4 rather than slowing the small kernels down.
-            HIPCHK(h, hipEventRecord(h->ev_fork2, s));
-            HIPCHK(h, hipStreamWaitEvent(h->aux, h->ev_fork2, 0));
-            for (auto& a : h->ops) {
-                if (!a.on_aux || a.aux_group != 1) continue;
-                SmallCinParams p = a.sc;
-                p.src = in_dev;
-                hipError_t e2 = launch_conv_smallcin(p, h->aux);
-                if (e2 != hipSuccess) return fail(h, MSR_ERR_DEVICE, "launch of conv_smallcin (aux) failed: %s", hipGetErrorString(e2));
-                if (a.done) HIPCHK(h, hipEventRecord(a.done, h->aux));
-            }
-        }
         if (gate && op_index == h->gate_op) {
             // msr_forward_gated: the matrix-bound part of this call starts only after the caller's event (the end of
             // the previous call on another handle / stream); everything before it overlaps that call's tail

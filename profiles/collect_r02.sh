@@ -36,7 +36,7 @@ python bench.py --streams 2 --no-cpu-baseline --no-also > $O/bench_2streams.json
 echo "bench done"
 # tile loop: trace by kernel family (idle gaps between tiles), end to end against generator-only
 rocprofv3 --kernel-trace --stats -d $O/kt_raster -o kt --output-format csv -- python3 raster_bench.py --image-size 512 --stride 64 --batch-size 8 --no-reference > $O/kt_raster.log 2>&1 || exit 1
-python profiles/trace_families.py $O/kt_raster/kt_kernel_trace.csv 0.55 > $O/raster512_families.txt || exit 1
+python profiles/trace_families.py $O/kt_raster/kt_kernel_trace.csv tiles > $O/raster512_families.txt || exit 1
 python raster_bench.py > $O/raster256.json 2> /dev/null || exit 1
 python raster_bench.py --image-size 512 --stride 64 --batch-size 8 > $O/raster512.json 2> /dev/null || exit 1
 (python tests/gpu_determinism_soak.py 512 8 200 && python tests/gpu_determinism_soak.py 256 16 300) > $O/determinism_soak.txt 2>&1 || exit 1

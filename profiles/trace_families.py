@@ -1,16 +1,23 @@
 """Per-family busy time of a rocprofv3 --kernel-trace CSV over a time window: total kernel time, union of the
 intervals (what the GPU was busy with at least one kernel of the family), and the idle time no kernel covers.
-usage: python profiles/trace_families.py <kernel_trace.csv> [skip_fraction_at_start]"""
+usage: python profiles/trace_families.py <kernel_trace.csv> [skip_fraction_at_start | tiles]
+"tiles": the window runs from the second patch_stats launch (the first belongs to the warm-up tile) to the end of the last
+stitch_tile launch, i.e. the timed tile loop of raster_bench.py."""
 import csv
 import sys
 
 path = sys.argv[1]
-skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
+mode = sys.argv[2] if len(sys.argv) > 2 else "0.0"
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(path))]
 rows.sort()
 t0, t1 = rows[0][0], max(r[1] for r in rows)
-w0 = t0 + int((t1 - t0) * skip)
-rows = [r for r in rows if r[0] >= w0]
+if mode == "tiles":
+    ps = [r[0] for r in rows if "patch_stats" in r[2]]
+    st = [r[1] for r in rows if "stitch_tile" in r[2]]
+    w0, t1 = ps[1], st[-1]
+else:
+    w0 = t0 + int((t1 - t0) * float(mode))
+rows = [r for r in rows if r[0] >= w0 and r[1] <= t1]
 span = (t1 - w0) / 1e6
 
 
