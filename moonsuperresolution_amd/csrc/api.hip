@@ -1171,7 +1171,7 @@ int ensure_plan(msr_handle* h) {
     h->ops.clear();
     drop_graphs(h);                       // they hold the old plan's pointers
     if (!h->aux) {
-        HIPCHK(h, hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+        HIPCHK(h, hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));   // (stream priority, low or high, changes nothing: measured)
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         // First use now: HIP binds a stream to a hardware queue when it is first used, in order, and queues whose ids
         // are equal modulo 4 share a dispatch pipe (profiles/r02_raster_queue_pairing.txt).  Callers that pipeline two

@@ -203,6 +203,59 @@ def test_sharded_map_with_the_real_process_tile(dsr):
     d.close(); gen.close()
 
 
+def test_config3_geometry_at_size_and_one_tile_of_a_shard(dsr):
+    """BASELINE configs[3]: the 15000 x 70000 raster of README.md:13 at the production settings of run_GAN.sh:24-26
+    (S = 512, s = 64, T = 1024).  Canvas 16256 x 71552, 15 x 69 = 1035 tiles, tile rows dealt 8 / 7 over 2 ranks,
+    4,4,4,3 over 4 and 2,2,2,2,2,2,2,1 over 8 (distributed.shard_tile_rows).  One tile of rank 3 of 8 is processed on the
+    full-size canvas (patches cut at offsets beyond 2^31 bytes) and must equal, bit for bit, the same tile processed
+    from a small raster that holds just its window: tiles are independent units (process_full_tiles.py:431-479)."""
+    from moonsuperresolution_amd import Generator
+    from moonsuperresolution_amd.distributed import shard_tile_rows
+    DEMSuperResolution, DSRConfig = dsr
+    S, s, T, B = 512, 64, 1024, 8
+    rows, cols = 15000, 70000
+    gen = Generator(S, B, variant="gaugan_no_kl", weights=1234)
+    cfg = DSRConfig(image_size=S, stride=s, batch_size=B, tile_size=T)
+    big = DEMSuperResolution(cfg, model=gen, pipeline=1)
+    # the padded canvases, built on the device (a smooth field + noise; nodata outside the raster as padInputs leaves it)
+    big.dem_shape = big.img_shape = (rows, cols)
+    hp, wp = ((rows // 1024) + 1) * 1024 + 2 * (S - s), ((cols // 1024) + 1) * 1024 + 2 * (S - s)
+    assert (hp, wp) == (16256, 71552)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    yy = torch.arange(hp, device="cuda", dtype=torch.float32)[:, None]
+    xx = torch.arange(wp, device="cuda", dtype=torch.float32)[None, :]
+    big.dem_padded = -2000 + 600 * torch.sin(xx / 370.0) * torch.cos(yy / 530.0) + torch.randn((hp, wp), generator=g, device="cuda")
+    big.img_padded = 0.5 + 0.3 * torch.cos(xx / 230.0) * torch.sin(yy / 310.0) + 0.05 * torch.randn((hp, wp), generator=g, device="cuda")
+    halo = S - s
+    for t in (big.dem_padded, big.img_padded):
+        t[:halo] = NOVAL; t[:, :halo] = NOVAL; t[halo + rows:] = NOVAL; t[:, halo + cols:] = NOVAL
+    big.dem_padded_shape = big.img_padded_shape = (hp, wp)
+    tiles = big.generateTileList()
+    assert len(tiles) == 1035 and len({y for _, y in tiles}) == 15 and len({x for x, _ in tiles}) == 69
+    for world, want in ((2, [8, 7]), (4, [4, 4, 4, 3]), (8, [2, 2, 2, 2, 2, 2, 2, 1])):
+        assert [len(shard_tile_rows(tiles, r, world)) // 69 for r in range(world)] == want
+    mine = shard_tile_rows(tiles, 3, 8)
+    assert len(mine) == 138 and mine[0] == (0, 6144)
+    px, py = mine[68]                                    # last tile of rank 3's first row: x = 69632, byte offsets > 2^31
+    assert (px, py) == (69632, 6144)
+    mean, std, good = big.processTile(px, py)
+    nv, ncall = big.last_counts
+    assert 0 < nv < 529 and ncall == -(-nv // B)         # the raster ends inside this tile: part of its patches is nodata
+    # the same tile from a raster that holds only its window
+    win = T + 2 * halo
+    small = DEMSuperResolution(cfg, model=gen, pipeline=1)
+    small.dem_shape = small.img_shape = (T, T)
+    small.dem_padded = big.dem_padded[py:py + win, px:px + win].contiguous()
+    small.img_padded = big.img_padded[py:py + win, px:px + win].contiguous()
+    small.dem_padded_shape = small.img_padded_shape = (win, win)
+    m2, s2, g2 = small.processTile(0, 0)
+    assert small.last_counts == (nv, ncall)
+    assert torch.equal(good, g2) and torch.equal(mean, m2) and torch.equal(std, s2) and bool(good.any())
+    big.close(); small.close(); gen.close()
+    del big, small
+    torch.cuda.empty_cache()
+
+
 def test_full_size_stitch_properties(dsr):
     """BASELINE geometry S=512, s=64, T=1024 (529 patches): constant predictions stitch to a constant."""
     DEMSuperResolution, DSRConfig = dsr
