@@ -144,6 +144,37 @@ def test_clone_and_pipeline_follow_loaded_weights(hip_lib):
     d1.close(); d2.close(); gen.close()
 
 
+@pytest.mark.parametrize("precision", ["f16c", "bf16x3"])
+def test_last_batch_of_a_tile_one_patch_and_seven_zero_patches(hip_lib, precision):
+    """process_full_tiles.py:468-474 at the production geometry: 529 patches in batches of 8 leave ONE real patch, padded
+    with seven all-zero patches that take part in SPADE's batch statistics (spade.py:21) — the most lopsided batch the
+    path produces (zero patches make the mask embedding, and with it gamma and beta, constant over 7/8 of the batch).
+    GauGAN(512, 8) against the fp32 oracle on exactly that batch."""
+    from moonsuperresolution_amd import Generator
+    from oracle import generator_ref
+    S, B = 512, 8
+    key = ("zeros", S, B)
+    if key not in _ORACLE:
+        _ORACLE.clear()
+        w = make_weights("gaugan", S, seed=1234, bias_scale=0.05)
+        eps = make_latent_noise(B, 256, 7)
+        x = synthetic_patches(B, S, 0)
+        x[1:] = 0.0
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        _ORACLE[key] = (x, w, eps, np.asarray(generator_ref.spade_call(x, w, "gaugan", eps, dtype=torch.float32), np.float64))
+    x, w, eps, ref = _ORACLE[key]
+    gen = Generator(S, B, variant="gaugan", weights=w, eps=eps, precision=precision)
+    y = gen(x, training=False)
+    err = rel_linf(y, ref)
+    err_real = rel_linf(y[0], ref[0])
+    _record(S=S, B=B, precision=precision, oracle="float32", batch="1 real + 7 zero patches", rel_linf_output=err,
+            rel_linf_real_patch=err_real)
+    gen.close()
+    del gen
+    torch.cuda.empty_cache()
+    assert np.isfinite(y).all() and err <= TOL and err_real <= TOL, (err, err_real)
+
+
 FP8_TOL = 0.25     # declared, NON-parity (measured 0.16 relative L-inf, 0.13 relative rms at both BASELINE sizes)
 
 
