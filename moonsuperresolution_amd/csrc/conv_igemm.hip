@@ -17,6 +17,7 @@
 //   Each wave owns MT x NT accumulator tiles of 32x32 (64 VGPRs for 2x2).
 //   The input tensor carries a physical zero border, so no bounds checks exist in the K loop.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace msr {
 
@@ -1668,6 +1669,7 @@ static hipError_t set_attr_halo() {
 hipError_t conv_igemm_init() {
     hipError_t e;
     if ((e = set_attr_halo()) != hipSuccess) return e;
+    if ((e = conv_sw_init()) != hipSuccess) return e;
     if ((e = set_attr_all<2, 2, 2, 2, 32, PREC_F32>()) != hipSuccess) return e;
     if ((e = set_attr_all<2, 1, 1, 2, 32, PREC_F32>()) != hipSuccess) return e;
     if ((e = set_attr_all<2, 2, 2, 2, 16, PREC_F32>()) != hipSuccess) return e;
@@ -1931,6 +1933,10 @@ static hipError_t launch_pp(const ConvParams& p, int epi, hipStream_t s) {
     }
     if (p.prec == PREC_F16C) {
         if (!p.wexp) return hipErrorInvalidValue;
+        // conv_sw.hip (one software-pipelined wave per SIMD) takes the long-K main convs; the gamma|beta convs stay here, where
+        // a second wave on the SIMD hides their SPADE epilogue.  MSR_F16C_SW = 0: everything here, 2: everything there (A/B).
+        static const int sw_mode = std::getenv("MSR_F16C_SW") ? std::atoi(std::getenv("MSR_F16C_SW")) : 1;
+        if (sw_mode == 2 || (sw_mode == 1 && epi != EPI_SPADE && p.Cin % 128 == 0)) return launch_conv_f16c_sw(p, epi, s);
         switch (epi) {
             case EPI_BIAS: conv_igemm_bf16x3_pp<EPI_BIAS, PP_F16C><<<grid, 512, PP_LDS, s>>>(p, g); break;
             case EPI_RES: conv_igemm_bf16x3_pp<EPI_RES, PP_F16C><<<grid, 512, PP_LDS, s>>>(p, g); break;

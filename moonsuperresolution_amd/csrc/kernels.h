@@ -185,6 +185,11 @@ __device__ inline void msr_store_f16c4_dev(float* pixel, int c, float v0, float 
 enum ConvTile : int { TILE_128x128 = 0, TILE_64x64 = 1, TILE_128x128_K16 = 2, TILE_128x128_HALO = 3, TILE_128x128_HALO16 = 4, TILE_256x128_PP = 5 };
 
 hipError_t conv_igemm_init();   // sets dynamic-LDS attributes once
+// conv_sw.hip: PREC_F16C whole-tile launches as one software-pipelined wave per SIMD.  launch_conv_igemm sends it the
+// long-K main convs (bias / residual epilogues, Cin % 128 == 0); MSR_F16C_SW = 0 keeps everything on the ping-pong kernel,
+// 2 sends the gamma|beta convs there too (A/B runs)
+hipError_t conv_sw_init();
+hipError_t launch_conv_f16c_sw(const ConvParams& p, int epilogue, hipStream_t s);
 hipError_t launch_conv_igemm(const ConvParams& p, int epilogue, int tile, hipStream_t s);
 // picks the tile and the K split for a problem size (fills the chip for the low-resolution layers)
 int conv_pick_tile(int M, int N, int epilogue, int prec, int ksteps = 0);
