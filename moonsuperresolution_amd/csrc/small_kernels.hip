@@ -299,41 +299,40 @@ size_t dense_partial_floats(int B, int K, int N) {
     return (size_t)((K + kch - 1) / kch) * B * N;
 }
 
+// NB = the batch rounded up to 1 / 2 / 4 / 8 / 16 rows: the first version always multiplied 16 rows, so a B = 1 call spent
+// 16x the FMAs and LDS reads its one row needs and the 268 MB encoder-head matrix streamed at 2.6 TB/s (VALU-bound).
+template <int NB>
 __global__ void __launch_bounds__(128) dense_partial_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                             float* __restrict__ partial, int B, int K, int N,
                                                             int kch) {
-    // x chunk as [k][16 rows]: the 16 row values of one k are four broadcast 16-byte LDS reads
-    __shared__ __attribute__((aligned(16))) float xs[DENSE_KCH * DENSE_MAXB];
+    // x chunk as [k][NB rows]: the row values of one k are broadcast LDS reads
+    __shared__ __attribute__((aligned(16))) float xs[DENSE_KCH * NB];
     const int col = (blockIdx.x * 128 + threadIdx.x) * 4;
     const int k0 = blockIdx.y * kch;
     const int kn = min(kch, K - k0);
-    for (int i = threadIdx.x; i < DENSE_MAXB * kch; i += 128) {
+    for (int i = threadIdx.x; i < NB * kch; i += 128) {
         const int b = i / kch, k = i % kch;
-        xs[k * DENSE_MAXB + b] = (b < B && k < kn) ? x[(size_t)b * K + k0 + k] : 0.f;
+        xs[k * NB + b] = (b < B && k < kn) ? x[(size_t)b * K + k0 + k] : 0.f;
     }
     __syncthreads();
     if (col >= N) return;
-    float4 acc[DENSE_MAXB];
+    float4 acc[NB];
 #pragma unroll
-    for (int b = 0; b < DENSE_MAXB; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = 0; b < NB; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* wp = W + (size_t)k0 * N + col;
 #pragma unroll 8
     for (int k = 0; k < kn; ++k) {
         const float4 w = *reinterpret_cast<const float4*>(wp + (size_t)k * N);
 #pragma unroll
-        for (int bq = 0; bq < DENSE_MAXB / 4; ++bq) {
-            const float4 xv = *reinterpret_cast<const float4*>(xs + k * DENSE_MAXB + bq * 4);
-            const float xr[4] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float4& a = acc[bq * 4 + e];
-                a.x = fmaf(xr[e], w.x, a.x); a.y = fmaf(xr[e], w.y, a.y);
-                a.z = fmaf(xr[e], w.z, a.z); a.w = fmaf(xr[e], w.w, a.w);
-            }
+        for (int b = 0; b < NB; ++b) {
+            const float xr = xs[k * NB + b];
+            float4& a = acc[b];
+            a.x = fmaf(xr, w.x, a.x); a.y = fmaf(xr, w.y, a.y);
+            a.z = fmaf(xr, w.z, a.z); a.w = fmaf(xr, w.w, a.w);
         }
     }
 #pragma unroll
-    for (int b = 0; b < DENSE_MAXB; ++b)
+    for (int b = 0; b < NB; ++b)
         if (b < B) *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.y * B + b) * N + col) = acc[b];
 }
 
@@ -345,8 +344,10 @@ __global__ void __launch_bounds__(256) dense_final_kernel(const float* __restric
     const int lane = threadIdx.x & 15, slot = threadIdx.x >> 4;
     const int i = blockIdx.x * 16 + lane;
     float s = 0.f;
-    if (i < B * N)
+    if (i < B * N) {
+#pragma unroll 8      // the loads of 8 slots in flight, the adds in the same order as before
         for (int k = slot; k < splits; k += 16) s += partial[(size_t)k * B * N + i];
+    }
     red[slot][lane] = s;
     __syncthreads();
     if (slot == 0 && i < B * N) {
@@ -360,7 +361,12 @@ hipError_t launch_dense(const float* x, const float* W, const float* bias, float
     if (B > DENSE_MAXB || N % 4) return hipErrorInvalidValue;
     const int kch = dense_kch(K, N);
     const int splits = (K + kch - 1) / kch;
-    dense_partial_kernel<<<dim3((N / 4 + 127) / 128, splits), 128, 0, s>>>(x, W, partial, B, K, N, kch);
+    const dim3 grid((N / 4 + 127) / 128, splits);
+    if (B <= 1) dense_partial_kernel<1><<<grid, 128, 0, s>>>(x, W, partial, B, K, N, kch);
+    else if (B <= 2) dense_partial_kernel<2><<<grid, 128, 0, s>>>(x, W, partial, B, K, N, kch);
+    else if (B <= 4) dense_partial_kernel<4><<<grid, 128, 0, s>>>(x, W, partial, B, K, N, kch);
+    else if (B <= 8) dense_partial_kernel<8><<<grid, 128, 0, s>>>(x, W, partial, B, K, N, kch);
+    else dense_partial_kernel<16><<<grid, 128, 0, s>>>(x, W, partial, B, K, N, kch);
     dense_final_kernel<<<(B * N + 15) / 16, 256, 0, s>>>(partial, bias, y, splits, B, N);
     return hipGetLastError();
 }

@@ -277,6 +277,14 @@ class DEMSuperResolution:
         lib, h, dev = self._lib, self._h, self.device
         if self._prep_stream is None:
             self._prep_stream = torch.cuda.Stream(dev)
+        # The padded rasters are produced on the caller's stream (padInputs, or tensors the caller built): the preparation
+        # stream must not read them before that work is done.  Once per raster pair — waiting on every tile would put
+        # tile t + 1's preparation behind tile t's generator calls and undo the pipelining.
+        token = (self.img_padded.data_ptr(), self.dem_padded.data_ptr(), getattr(self.img_padded, "_version", 0),
+                 getattr(self.dem_padded, "_version", 0))
+        if getattr(self, "_raster_token", None) != token:
+            self._prep_stream.wait_stream(torch.cuda.current_stream(dev))
+            self._raster_token = token
         rows, cols = self.dem_padded_shape
         span = T + S - s
         st = {"px": px, "py": py}

@@ -356,3 +356,17 @@ def test_conv_f16c_spade_epilogue_writes_the_chunk_image(ctx):
     assert float(((h8 - want).abs() / want.abs().clamp_min(2.0 ** -6)).max()) <= 2.0 ** -4 * 1.01   # h8 = e4m3 of the value
     full = ops.f16c_decode(yc)
     assert float(full[0][:, 0].abs().max()) == 0 and float(full[1][:, :, -1].abs().max()) == 0     # the border stays zero
+
+
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_f16c_convs_under_the_other_kernel_dispatch(mode):
+    """PREC_F16C launches go to the stream kernel (conv_sw.hip) for the bias / residual epilogues and to the ping-pong kernel
+    for the SPADE epilogue by default; MSR_F16C_SW (read once per process) = 0 sends everything to the ping-pong kernel, 2
+    everything to the stream kernel.  The f16c kernel tests above must hold under both: run them in a child process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MSR_F16C_SW=mode)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "f16c and not other_kernel_dispatch"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
