@@ -405,13 +405,74 @@ __device__ __forceinline__ void halo16_epilogue_body(const ConvParams& p, f32x4 
     }
 }
 
+// EPI_SPADE writing the f16c chunk image, assembled per pixel in LDS.  A lane's 4 channels are three pieces of the pixel's
+// 128-byte chunk (8 bytes of fp16, 4 of h8, 4 of l8): stored straight from the lane that is SIX store instructions per tile
+// row, each touching 16 lines with 4- or 8-byte pieces, and the epilogue is store-ISSUE-bound (tests/gpu_pp_stamps_gb.py: a
+// gamma|beta tile takes 87.4k cycles, 79.4k with one 16-byte store per lane, 77.4k with none; MI355X_MICROARCH.md
+// "epilogue store tail").  Here the wave writes the pieces of one tile row (16 pixels x 32 channels = 16 chunk lines) into
+// a private 2.3 KB LDS image, reads each line back as two 16-byte quarters per lane and issues TWO stores per row, each
+// 64 contiguous bytes per pixel.  Private to the wave (LDS operations of one wave execute in order): no barrier.
+__device__ __forceinline__ void halo16_epilogue_spade_f16c_staged(const ConvParams& p, f32x4 (&acc)[4][4], int wm, int wn,
+                                                                  int lane, int n0, int tx0, int ty0, int b0,
+                                                                  float4 (&xin)[4][2], float4 (&cv)[8], unsigned* stage) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    constexpr int SP = 36;                                     // dwords per staged line (32 + pad: spreads the pixels over banks)
+    const int px = lane & 15, cg = lane >> 4;
+    const int x = tx0 + px, y0 = ty0 + wm * 4;
+    const int ch0 = (n0 + wn * 64) >> 1;                       // first of the wave's 32 output channels: one whole chunk
+    float* const obase = p.out + (size_t)p.out_off + (size_t)b0 * p.out_pb + x * p.out_px + ch0;
+    unsigned* const line = stage + px * SP;
+    float rs[2][4];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        rs[jj][0] = 1.f / cv[6 + jj].x; rs[jj][1] = 1.f / cv[6 + jj].y; rs[jj][2] = 1.f / cv[6 + jj].z; rs[jj][3] = 1.f / cv[6 + jj].w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const float gq[4] = {cv[jj].x, cv[jj].y, cv[jj].z, cv[jj].w};
+            const float bq[4] = {cv[2 + jj].x, cv[2 + jj].y, cv[2 + jj].z, cv[2 + jj].w};
+            const float mq[4] = {cv[4 + jj].x, cv[4 + jj].y, cv[4 + jj].z, cv[4 + jj].w};
+            const float xq[4] = {xin[i][jj].x, xin[i][jj].y, xin[i][jj].z, xin[i][jj].w};
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float normalized = (xq[k] - mq[k]) * rs[jj][k];
+                const float t = (acc[i][jj][k] + gq[k]) * normalized + (acc[i][jj + 2][k] + bq[k]);
+                v[k] = t >= 0.f ? t : t * p.slope;
+                v[k] = v[k] > 65504.f ? 65504.f : (v[k] < -65504.f ? -65504.f : v[k]);     // as msr_store_f16c4_dev
+            }
+            const h2 a = {(_Float16)v[0], (_Float16)v[1]}, b = {(_Float16)v[2], (_Float16)v[3]};
+            unsigned h8 = 0, l8 = 0;
+            h8 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], h8, false);
+            h8 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], h8, true);
+            l8 = __builtin_amdgcn_cvt_pk_fp8_f32((v[0] - (float)a[0]) * 2048.f, (v[1] - (float)a[1]) * 2048.f, l8, false);
+            l8 = __builtin_amdgcn_cvt_pk_fp8_f32((v[2] - (float)b[0]) * 2048.f, (v[3] - (float)b[1]) * 2048.f, l8, true);
+            // the chunk image of the pixel: dwords 0..15 fp16 pairs, 16..23 h8, 24..31 l8 (channel 16 jj + 4 cg + {0..3})
+            *reinterpret_cast<uint2*>(line + jj * 8 + 2 * cg) = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+            line[16 + jj * 4 + cg] = h8;
+            line[24 + jj * 4 + cg] = l8;
+        }
+        // quarter cg of each half of the line (compiler barriers: the pieces were written through other types)
+        asm volatile("" ::: "memory");
+        const uint4 q0 = *reinterpret_cast<const uint4*>(line + 4 * cg);
+        const uint4 q1 = *reinterpret_cast<const uint4*>(line + 16 + 4 * cg);
+        asm volatile("" ::: "memory");
+        unsigned* orow = reinterpret_cast<unsigned*>(obase + (y0 + i) * p.out_py);
+        *reinterpret_cast<uint4*>(orow + 4 * cg) = q0;
+        *reinterpret_cast<uint4*>(orow + 16 + 4 * cg) = q1;
+    }
+}
+
 template <int EPI>
 __device__ __forceinline__ void halo16_epilogue(const ConvParams& p, const TileGeom& g, f32x4 (&acc)[4][4], int wm, int wn,
                                                 int lane, int n0, int tx0, int ty0, int b0, float4 (&xin)[4][2],
-                                                float4 (&cv)[8]) {
+                                                float4 (&cv)[8], unsigned* stage = nullptr) {
     const int stat_tile = (b0 * g.tiles_y + (ty0 >> g.th_l)) * g.tiles_x + (tx0 >> g.tw_l);
     if constexpr (EPI == EPI_SPADE) {
-        if (p.out_split == 4) halo16_epilogue_body<EPI, true, false, true>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile, xin, cv);
+        if (p.out_split == 4 && stage) halo16_epilogue_spade_f16c_staged(p, acc, wm, wn, lane, n0, tx0, ty0, b0, xin, cv, stage);
+        else if (p.out_split == 4) halo16_epilogue_body<EPI, true, false, true>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile, xin, cv);
         else if (p.out_split == 3) halo16_epilogue_body<EPI, true, true>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile, xin, cv);
         else if (p.out_split) halo16_epilogue_body<EPI, true>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile, xin, cv);
         else halo16_epilogue_body<EPI, false>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile, xin, cv);
@@ -1143,6 +1204,13 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // PP_F16C + EPI_SPADE: a private 16 x 36-dword line image per wave behind the tile buffers (epilogue store assembly)
+#ifdef MSR_PP_STAMPS
+    unsigned* const stage = nullptr;              // the stamp words live there in the diagnostic build
+#else
+    unsigned* const stage = (MODE == PP_F16C && EPI == EPI_SPADE)
+        ? reinterpret_cast<unsigned*>(smem + (2 * HP + 2 * BN) * BKP) + wave * (16 * 36) : nullptr;
+#endif
     const int grp = wave >> 2;                    // 0 = X, 1 = Y (wave-uniform, scalar)
     const int wm = (wave >> 1) & 1, wn = wave & 1;
 
@@ -1432,7 +1500,14 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
     TileGeom ge = g;                              // the epilogue numbers its moment slabs by 8-row tiles
     ge.th_l = 3;
     ge.tiles_y = g.tiles_y * 2;
+#ifdef MSR_PP_STAMPS
+    unsigned tstamp[20];
+    int tstamp_n = 0;
+#endif
     for (;;) {
+#ifdef MSR_PP_STAMPS
+        if (tstamp_n < 20) tstamp[tstamp_n++] = (unsigned)__builtin_amdgcn_s_memtime();      // coarse: one stamp per tile
+#endif
         const int tnext = ONE ? tile + 2 * slots : tile + slots;
         const bool has_next = tnext < cnt;
         int n0n, tx0n, ty0n, b0n, ks0n;
@@ -1482,7 +1557,7 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
         } else {
             if constexpr (MODE == PP_FP8 || MODE == PP_F16C) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0);
             if constexpr (EPI == EPI_PARTIAL) halo16_epilogue_partial(p, acc, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0, ks0);
-            else halo16_epilogue<EPI>(p, ge, acc, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0, xpre, cpre);
+            else halo16_epilogue<EPI>(p, ge, acc, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0, xpre, cpre, stage);
         }
         if (!has_next) break;
         tile = tnext;
@@ -1492,6 +1567,7 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
     }
 #ifdef MSR_PP_STAMPS
     if (blockIdx.x == 8 && lane == 0 && (wave & 3) == 0) {
+        for (int k = 0; k + 1 < tstamp_n; ++k) printf("wave %d tile %2d: %6u cycles\n", wave, k, tstamp[k + 1] - tstamp[k]);
         const unsigned* d = dbg + (wave >> 2) * 1024;
         for (int k = 0; k + 3 < dbg_n; k += 4)
             printf("wave %d step %2d: R %4u  barrier %4u  M %4u  barrier+next %4u cycles\n", wave, k / 4, d[k + 1] - d[k],
@@ -1641,6 +1717,12 @@ static constexpr size_t PP_LDS = (size_t)(2 * 324 + 2 * 128) * 40 * sizeof(float
 #else
 static constexpr size_t PP_LDS = (size_t)(2 * 324 + 2 * 128) * 40 * sizeof(float);
 #endif
+// PP_F16C + EPI_SPADE launches: + 8 waves x 16 lines x 36 dwords of epilogue store assembly = 163,072 B of the CU's 163,840
+#ifdef MSR_PP_STAMPS
+static constexpr size_t PP_STAGE_LDS = 0;
+#else
+static constexpr size_t PP_STAGE_LDS = (size_t)8 * 16 * 36 * sizeof(unsigned);
+#endif
 
 static hipError_t set_attr_halo() {
     hipError_t e;
@@ -1652,7 +1734,10 @@ static hipError_t set_attr_halo() {
     MSR_SETPP(EPI_SPADE, PP_F16X2) MSR_SETPP(EPI_PARTIAL, PP_BF16X3)
     MSR_SETPP(EPI_BIAS, PP_FP8) MSR_SETPP(EPI_RES, PP_FP8) MSR_SETPP(EPI_SPADE, PP_FP8)
     MSR_SETPP(EPI_BIAS, PP_FP8, true) MSR_SETPP(EPI_RES, PP_FP8, true) MSR_SETPP(EPI_SPADE, PP_FP8, true)
-    MSR_SETPP(EPI_BIAS, PP_F16C) MSR_SETPP(EPI_RES, PP_F16C) MSR_SETPP(EPI_SPADE, PP_F16C)
+    MSR_SETPP(EPI_BIAS, PP_F16C) MSR_SETPP(EPI_RES, PP_F16C)
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_pp<EPI_SPADE, PP_F16C>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PP_LDS + PP_STAGE_LDS))) != hipSuccess)
+        return e;
 #undef MSR_SETPP
 #define MSR_SET(EPI)                                                                                          \
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_halo<EPI, 0>),               \
@@ -1940,7 +2025,7 @@ static hipError_t launch_pp(const ConvParams& p, int epi, hipStream_t s) {
         switch (epi) {
             case EPI_BIAS: conv_igemm_bf16x3_pp<EPI_BIAS, PP_F16C><<<grid, 512, PP_LDS, s>>>(p, g); break;
             case EPI_RES: conv_igemm_bf16x3_pp<EPI_RES, PP_F16C><<<grid, 512, PP_LDS, s>>>(p, g); break;
-            case EPI_SPADE: conv_igemm_bf16x3_pp<EPI_SPADE, PP_F16C><<<grid, 512, PP_LDS, s>>>(p, g); break;
+            case EPI_SPADE: conv_igemm_bf16x3_pp<EPI_SPADE, PP_F16C><<<grid, 512, PP_LDS + PP_STAGE_LDS, s>>>(p, g); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();

@@ -172,12 +172,20 @@ __device__ inline void msr_store_f16c4_dev(float* pixel, int c, float v0, float 
     const float l0 = v0 - (float)a[0], l1 = v1 - (float)a[1], l2 = v2 - (float)b[0], l3 = v3 - (float)b[1];
     unsigned* chunk = reinterpret_cast<unsigned*>(pixel) + (c & ~31);
     const int cc = c & 31;
-    *reinterpret_cast<uint2*>(chunk + (cc >> 1)) = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
     unsigned h8 = 0, l8 = 0;
     h8 = __builtin_amdgcn_cvt_pk_fp8_f32(v0, v1, h8, false);
     h8 = __builtin_amdgcn_cvt_pk_fp8_f32(v2, v3, h8, true);
     l8 = __builtin_amdgcn_cvt_pk_fp8_f32(l0 * 2048.f, l1 * 2048.f, l8, false);
     l8 = __builtin_amdgcn_cvt_pk_fp8_f32(l2 * 2048.f, l3 * 2048.f, l8, true);
+#ifdef MSR_WI_ONESTORE   // what-if build (wrong layout): the lane's 16 bytes as one store
+    *reinterpret_cast<uint4*>(chunk + cc) = make_uint4(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), h8, l8);
+    return;
+#endif
+#ifdef MSR_WI_NOSTORE    // what-if build (no output)
+    asm volatile("" : : "v"(h8), "v"(l8), "v"(chunk));
+    return;
+#endif
+    *reinterpret_cast<uint2*>(chunk + (cc >> 1)) = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
     chunk[16 + (cc >> 2)] = h8;                                    // bytes 64..95: h8 of the 32 channels
     chunk[24 + (cc >> 2)] = l8;                                    // bytes 96..127: l8
 }
