@@ -1163,7 +1163,8 @@ conv_igemm_bf16x3_halo(const ConvParams p, const TileGeom g) {
 // weight tile double-buffered by K-step, 160-byte rows: 2 * 324 * 160 + 2 * 128 * 160 = 144,640 B.
 // Barrier count (s_barrier only counts arrivals; every wave must execute the same number): per K-step each wave
 // runs two (after R, after M); group Y runs one extra before its first R and skips the one after its last M of the
-// workgroup's last tile: X = 1 + 2 * steps, Y = 1 + 1 + 2 * steps - 1 — equal.  (MSR_WG_BARRIER, top of the file.)
+// workgroup's last tile: X = 1 + 2 * steps, Y = 1 + 1 + 2 * steps - 1 — equal.  (MSR_WG_BARRIER, top of the file.)  On a
+// tile's last step Y executes its second barrier AFTER its epilogue (X before): same count, and the two epilogues overlap.
 // Hazards (b = barrier at the end of a phase): the weights of step t+1 go to Bs[(t+1)&1] during R(t) of both
 // groups (phases 2t, 2t+1); that buffer was last read in R(t-1) (phases 2t-2, 2t-1) and is next read in R(t+1)
 // (phases 2t+2, 2t+3).  The halo of chunk c+1 goes to Ah[(c+1)&1] on tap 7 of chunk c.
@@ -1462,8 +1463,11 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
         MSR_M(T)                                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         MSR_STAMP()                                                                              \
-        /* Y's M on the workgroup's very last step has no partner segment */                     \
-        if (!((LASTP) && (T) == 17) || has_next || grp == 0) MSR_WG_BARRIER()                    \
+        /* Y's M on the workgroup's very last step has no partner segment.  On a tile's last step (not ONE) group Y    \
+           postpones this barrier until after its epilogue (below the pair), so that both groups' epilogues share ONE \
+           barrier interval */                                                                   \
+        if (ONE || !((LASTP) && (T) == 17)) MSR_WG_BARRIER()                                     \
+        else if (grp == 0) MSR_WG_BARRIER()                                                      \
         if constexpr (ONE) {                                                                     \
             if ((T) == 8) {   /* item A is complete: its epilogue, fresh accumulators, item B's weight scales */ \
                 if constexpr (MODE == PP_FP8) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0); \
@@ -1547,8 +1551,11 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
             w_pair += 2 * BKC * 4;
         }
         MSR_PAIR(true)
-        // The epilogue of a tile shares a barrier interval with R(0) of the next one: X runs it beside Y's last M,
-        // Y beside X's first M of the next tile.  Its stores are not waited for.
+        // Both groups run their epilogue in the SAME barrier interval: X after the barrier that follows its last M (beside
+        // its R(0) of the next tile), Y right after its last M, BEFORE that barrier.  (Each group used to run it after the
+        // barrier: X's epilogue then faced only Y's last M and Y's only X's first M of the next tile, i.e. the two
+        // epilogues — ~10k cycles each with their loads and stores — ran one after the other: a gamma|beta tile took 87k
+        // cycles for 58k of K loop, tests/gpu_pp_stamps_gb.py.)  Its stores are not waited for.
         // PP_FP8: the scaled MFMA does not accumulate in place under register pressure, so its epilogue operands are
         // not held across the last K-steps but requested here
         if constexpr (ONE) {       // the body's second item
@@ -1558,6 +1565,7 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
             if constexpr (MODE == PP_FP8 || MODE == PP_F16C) halo16_epilogue_load<EPI>(p, xpre, cpre, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0);
             if constexpr (EPI == EPI_PARTIAL) halo16_epilogue_partial(p, acc, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0, ks0);
             else halo16_epilogue<EPI>(p, ge, acc, wm, wn, lane, n0, tx0, ty0 + grp * 8, b0, xpre, cpre, stage);
+            if (grp == 1 && has_next) MSR_WG_BARRIER()        // Y's barrier of the tile's last step (see MSR_STEP)
         }
         if (!has_next) break;
         tile = tnext;
