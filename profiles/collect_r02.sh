@@ -12,6 +12,14 @@ for cfg in "spade512 f16c" "spade512 bf16x3" "spade512 bf16x3_gbf16" "spade512 f
   cp $O/kt_${wl}_$pr/kt_kernel_stats.csv $O/${wl}_${pr}_kernel_stats.csv
   echo "trace $wl $pr done"
 done
+# the same default workload with every f16c launch on the ping-pong kernel (MSR_F16C_SW=0): what the stream kernel buys
+MSR_F16C_SW=0 rocprofv3 --kernel-trace --stats -d $O/kt_spade512_f16c_pp -o kt --output-format csv -- python3 profiles/run_forwards.py spade512 25 f16c > $O/kt_spade512_f16c_pp.log 2>&1 || exit 1
+python profiles/analyze_trace.py $O/kt_spade512_f16c_pp/kt_kernel_trace.csv 512 8 > $O/spade512_f16c_pponly_conv_layers.txt || exit 1
+# single-tile latency path: per-layer table at B = 1
+rocprofv3 --kernel-trace --stats -d $O/kt_b1 -o kt --output-format csv -- python3 profiles/run_forwards_b1.py 512 25 f16c > $O/kt_b1.log 2>&1 || exit 1
+python profiles/analyze_trace.py $O/kt_b1/kt_kernel_trace.csv 512 1 > $O/spade512_b1_f16c_conv_layers.txt || exit 1
+cp $O/kt_b1/kt_kernel_stats.csv $O/spade512_b1_f16c_kernel_stats.csv
+echo "pp-only and B=1 traces done"
 # HBM traffic of the default workload: separate PMC passes
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace -d $O/pmc_$c -o p --output-format csv -- python3 profiles/run_forwards.py spade512 3 f16c > $O/pmc_$c.log 2>&1 || exit 1

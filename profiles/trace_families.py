@@ -22,7 +22,7 @@ span = (t1 - w0) / 1e6
 
 
 def fam(name):
-    for key in ("conv_igemm_bf16x3_pp", "conv_igemm_bf16x3_halo", "conv_igemm_bf16x3", "conv_igemm", "splitk_epilogue",
+    for key in ("conv_igemm_f16c_sw", "conv_igemm_bf16x3_pp", "conv_igemm_bf16x3_halo", "conv_igemm_bf16x3", "conv_igemm", "splitk_epilogue",
                 "conv_smallcin", "moments", "norm_act", "dense", "latent", "head_kernel", "patch_stats", "extract_patches",
                 "compact_patches", "stitch", "fillBuffer", "copyBuffer"):
         if key in name:
