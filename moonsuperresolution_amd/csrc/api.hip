@@ -312,9 +312,18 @@ bool main_uses_fp8(msr_handle* h, int rout, int cin, int cout) {
 int upload(msr_handle* h, const std::string& key, const float* host, size_t floats);
 // MSR_FLAG_F16C: same coverage rule as the fp8 mode (whole-tile ping-pong launches; a main conv only if the gamma|beta
 // conv that writes its input is one too)
-bool gb_uses_f16c(msr_handle* h, int rout, int C) { return h->f16c && conv_fills_pp(h->B, rout, 2 * C); }
+// Since the second half of round 2 the K-range launches of the ping-pong kernel (fewer tiles than CUs: rb2 at the BASELINE
+// sizes, most layers of a B = 1 call) run the f16c form too, their split-K epilogue writes the f16c image
+// (MSR_F16C_KSPLIT=0: the earlier rule, whole-tile launches only).
+int pp_ksplit(int B, int rout, int N, int stride, int cin, long min_items);
+bool conv_on_pp_f16c(int B, int rout, int N, int cin) {
+    static const bool ks_off = std::getenv("MSR_F16C_KSPLIT") && std::atoi(std::getenv("MSR_F16C_KSPLIT")) == 0;
+    if (ks_off) return conv_fills_pp(B, rout, N);
+    return pp_ksplit(B, rout, N, 1, cin, 128) >= 1;
+}
+bool gb_uses_f16c(msr_handle* h, int rout, int C) { return h->f16c && conv_on_pp_f16c(h->B, rout, 2 * C, 128); }
 bool main_uses_f16c(msr_handle* h, int rout, int cin, int cout) {
-    return h->f16c && cin % 64 == 0 && conv_fills_pp(h->B, rout, cout) && conv_fills_pp(h->B, rout, 2 * cin);
+    return h->f16c && cin % 64 == 0 && conv_on_pp_f16c(h->B, rout, cout, cin) && conv_on_pp_f16c(h->B, rout, 2 * cin, 128);
 }
 
 // f16c image of [taps][N][Cin] weights (kernels.h PREC_F16C): per 32-channel chunk [32 x hi f16 | 32 x l8 | 32 x h8]
@@ -712,7 +721,8 @@ int alloc_padded(msr_handle* h, const std::string& key, int r, int C, Padded* ou
 // per range, a power of two, as many ranges as it takes to give every CU a work item.  0 = the layer is not one for
 // that kernel (it needs stride 1, r >= 16, Cin % 64 == 0, an input below the 2 GiB buffer-descriptor range and, split
 // or not, at least `min_items` work items — below that the small-tile split-K kernels are faster).
-int pp_ksplit(int B, int rout, int N, int stride, int cin, long min_items = 128) {
+int pp_ksplit(int B, int rout, int N, int stride, int cin, long min_items = 128);
+int pp_ksplit(int B, int rout, int N, int stride, int cin, long min_items) {
     static const bool off = std::getenv("MSR_PP_KSPLIT") && std::atoi(std::getenv("MSR_PP_KSPLIT")) == 0;
     if (stride != 1 || rout < 16 || cin % 64 || N % 128) return 0;
     if ((size_t)B * (rout + 2) * (rout + 2) * cin * sizeof(float) >= ((size_t)1 << 31)) return 0;
@@ -938,7 +948,7 @@ int plan_spade(msr_handle* h) {
                 gb.conv.prec = PREC_F16C;
                 gb.conv.wexp = reinterpret_cast<const int*>(need(k));
                 gb.tile = TILE_256x128_PP;
-                gb.conv.ksplit = 1;
+                gb.conv.ksplit = pp_ksplit(B, r, 2 * C, 1, 128);      // > 1: K ranges (fewer tiles than CUs)
                 gb.conv.wt_frag = 0;
             }
             if (cv8) gb.conv.out_split = 3;           // its epilogue writes bf8 bytes for the fp8 consumer
@@ -966,7 +976,7 @@ int plan_spade(msr_handle* h) {
                 cv.conv.prec = PREC_F16C;
                 cv.conv.wexp = reinterpret_cast<const int*>(need(k));
                 cv.tile = TILE_256x128_PP;
-                cv.conv.ksplit = 1;
+                cv.conv.ksplit = pp_ksplit(B, r, f, 1, C);
                 cv.conv.wt_frag = 0;
             }
             set_out_dense(cv.conv, y, r, f);

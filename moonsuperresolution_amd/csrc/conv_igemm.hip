@@ -1667,7 +1667,8 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(const ConvParams p
             }
         }
         float* opix = p.out + (size_t)p.out_off + (size_t)b * p.out_pb + (size_t)y * p.out_py + (size_t)x * p.out_px;
-        if (EPI == EPI_SPADE && p.out_split) msr_store_split4_dev(opix, c, v.x, v.y, v.z, v.w);
+        if (EPI == EPI_SPADE && p.out_split == 4) msr_store_f16c4_dev(opix, c, v.x, v.y, v.z, v.w);
+        else if (EPI == EPI_SPADE && p.out_split) msr_store_split4_dev(opix, c, v.x, v.y, v.z, v.w);
         else *reinterpret_cast<float4*>(opix + c) = v;
     }
 }
@@ -1742,7 +1743,7 @@ static hipError_t set_attr_halo() {
     MSR_SETPP(EPI_SPADE, PP_F16X2) MSR_SETPP(EPI_PARTIAL, PP_BF16X3)
     MSR_SETPP(EPI_BIAS, PP_FP8) MSR_SETPP(EPI_RES, PP_FP8) MSR_SETPP(EPI_SPADE, PP_FP8)
     MSR_SETPP(EPI_BIAS, PP_FP8, true) MSR_SETPP(EPI_RES, PP_FP8, true) MSR_SETPP(EPI_SPADE, PP_FP8, true)
-    MSR_SETPP(EPI_BIAS, PP_F16C) MSR_SETPP(EPI_RES, PP_F16C)
+    MSR_SETPP(EPI_BIAS, PP_F16C) MSR_SETPP(EPI_RES, PP_F16C) MSR_SETPP(EPI_PARTIAL, PP_F16C)
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_pp<EPI_SPADE, PP_F16C>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PP_LDS + PP_STAGE_LDS))) != hipSuccess)
         return e;
@@ -2008,8 +2009,13 @@ static hipError_t launch_pp(const ConvParams& p, int epi, hipStream_t s) {
     const int grid = items < n_cu ? ((items + 7) & ~7) : n_cu;
     if (ksn > 1) {
         // few tiles: K ranges fill the chip, raw accumulators go to the split-K workspace, one more pass finishes
-        if (!p.partial || p.prec != PREC_BF16X3) return hipErrorInvalidValue;     // K ranges exist in the 3-term form only
-        conv_igemm_bf16x3_pp<EPI_PARTIAL, PP_BF16X3><<<grid, 512, PP_LDS, s>>>(p, g);
+        if (!p.partial || (p.prec != PREC_BF16X3 && p.prec != PREC_F16C)) return hipErrorInvalidValue;     // K ranges: 3-term and f16c forms
+        if (p.prec == PREC_F16C) {
+            if (!p.wexp) return hipErrorInvalidValue;
+            conv_igemm_bf16x3_pp<EPI_PARTIAL, PP_F16C><<<grid, 512, PP_LDS, s>>>(p, g);
+        } else {
+            conv_igemm_bf16x3_pp<EPI_PARTIAL, PP_BF16X3><<<grid, 512, PP_LDS, s>>>(p, g);
+        }
         const int Cout = epi == EPI_SPADE ? p.N / 2 : p.N;
         long eb = ((long)p.B * p.Hout * p.Wout * (Cout / 4) + 255) / 256;
         if (eb > 4096) eb = 4096;
