@@ -326,6 +326,64 @@ bool main_uses_f16c(msr_handle* h, int rout, int cin, int cout) {
     return h->f16c && cin % 64 == 0 && conv_on_pp_f16c(h->B, rout, cout, cin) && conv_on_pp_f16c(h->B, rout, 2 * cin, 128);
 }
 
+// PREC_F16C6 (fp6 cross terms, kernels.h), OPT-IN with MSR_F16C_FP6=1: the main convs that run the stream kernel (conv_sw.hip:
+// whole tiles, Cin % 128 == 0) behind a gamma|beta conv that is a whole-tile ping-pong launch (its LDS-assembled epilogue
+// writes the fp6 image).  Measured: the consumer gains 6.5 % on those convs, the producer's block-scale and 6-bit
+// packing cost the gamma|beta epilogues more, net -1 % per call — it pays only once the gamma|beta convs consume fp6 too.
+// Any MSR_F16C_SW other than 1 (the A/B dispatches) switches it off.
+bool main_uses_f16c6(msr_handle* h, int rout, int cin, int cout) {
+    static const bool off = !(std::getenv("MSR_F16C_FP6") && std::atoi(std::getenv("MSR_F16C_FP6")) == 1) ||
+                            (std::getenv("MSR_F16C_SW") && std::atoi(std::getenv("MSR_F16C_SW")) != 1);
+    return !off && main_uses_f16c(h, rout, cin, cout) && cin % 128 == 0 && conv_fills_pp(h->B, rout, cout) &&
+           conv_fills_pp(h->B, rout, 2 * cin);
+}
+
+// f16c6 image of [taps][N][Cin] weights (kernels.h PREC_F16C6): per 32-channel chunk [32 x hi f16 | 24 B l6 | e8m0 | 0.. |
+// 24 B h6 | e8m0 | 0..], one power-of-two scale per output channel and piece (2^E >= max / 7.5)
+int upload_conv_weight_f16c6(msr_handle* h, const std::string& key, const float* host, int taps, int N, int Cin) {
+    if (Cin % 32) return fail(h, MSR_ERR_INVALID, "%s: f16c6 needs Cin %% 32 == 0", key.c_str());
+    std::vector<float> img((size_t)taps * N * Cin, 0.f);
+    auto pow2exp = [](float amax) {
+        if (!(amax > 0.f)) return 0;
+        int fe;
+        const float m = std::frexp(amax / 7.5f, &fe);       // amax / 7.5 = m * 2^fe, m in [0.5, 1)
+        return std::max(-100, std::min(100, m == 0.5f ? fe - 1 : fe));
+    };
+    for (int n = 0; n < N; ++n) {
+        float ah = 0.f, al = 0.f;
+        for (int t = 0; t < taps; ++t)
+            for (int k = 0; k < Cin; ++k) {
+                const float w = host[((size_t)t * N + n) * Cin + k];
+                const float hi = (float)(_Float16)w;
+                ah = std::max(ah, std::fabs(w));
+                al = std::max(al, std::fabs(w - hi));
+            }
+        const int eh = pow2exp(ah), el = pow2exp(al);
+        const float ih = std::ldexp(1.f, -eh), il = std::ldexp(1.f, -el);
+        for (int t = 0; t < taps; ++t)
+            for (int c0 = 0; c0 < Cin; c0 += 32) {
+                unsigned char* chunk = reinterpret_cast<unsigned char*>(img.data() + ((size_t)t * N + n) * Cin + c0);
+                unsigned long long bl[3] = {0, 0, 0}, bh[3] = {0, 0, 0};      // 192-bit little-endian strings
+                for (int c = 0; c < 32; ++c) {
+                    const float w = host[((size_t)t * N + n) * Cin + c0 + c];
+                    const _Float16 hi = (_Float16)w;
+                    reinterpret_cast<_Float16*>(chunk)[c] = hi;
+                    const unsigned long long cl = msr_f32_to_e2m3((w - (float)hi) * il), ch = msr_f32_to_e2m3(w * ih);
+                    const int pos = 6 * c;
+                    bl[pos / 64] |= cl << (pos % 64);
+                    if (pos % 64 > 58) bl[pos / 64 + 1] |= cl >> (64 - pos % 64);
+                    bh[pos / 64] |= ch << (pos % 64);
+                    if (pos % 64 > 58) bh[pos / 64 + 1] |= ch >> (64 - pos % 64);
+                }
+                std::memcpy(chunk + 64, bl, 24);
+                chunk[88] = (unsigned char)(127 + el);
+                std::memcpy(chunk + 96, bh, 24);
+                chunk[120] = (unsigned char)(127 + eh);
+            }
+    }
+    return upload(h, key, img.data(), img.size());
+}
+
 // f16c image of [taps][N][Cin] weights (kernels.h PREC_F16C): per 32-channel chunk [32 x hi f16 | 32 x l8 | 32 x h8]
 // with hi = f16_rn(w), l8 = e4m3((w - hi) * 2^-el), h8 = e4m3(w * 2^-eh), el / eh powers of two
 // per output channel; key + ".wexp"[n] = (127 + el) | (127 + eh) << 8
@@ -684,6 +742,7 @@ int msr_load_weight(msr_handle* h, const char* name_c, const float* host, const 
         int rout = 0, stride = 1;
         const bool gen_conv = name.rfind("gen.rb", 0) == 0 && weight_conv_shape(h, name, &rout, &stride);
         if (gen_conv && main_uses_fp8(h, rout, cin, cout)) rc = upload_conv_weight_fp8(h, name, t.data(), taps, cout, cin);
+        else if (gen_conv && main_uses_f16c6(h, rout, cin, cout)) rc = upload_conv_weight_f16c6(h, name, t.data(), taps, cout, cin);
         else if (gen_conv && main_uses_f16c(h, rout, cin, cout)) rc = upload_conv_weight_f16c(h, name, t.data(), taps, cout, cin);
         else
             rc = upload_conv_weight(h, name, t.data(), count, taps, cout, cin, weight_uses_frag(h, name, cout, EPI_BIAS, cin));
@@ -910,7 +969,7 @@ int plan_spade(msr_handle* h) {
             // MSR_FLAG_FP8: tensors that feed an fp8 conv hold one byte per channel, padded to 256 channels; the kernels
             // address them in float slots of 4 channels
             const bool gb8 = gb_uses_fp8(h, r, C), cv8 = main_uses_fp8(h, r, C, f);
-            const bool gbc = gb_uses_f16c(h, r, C), cvc = main_uses_f16c(h, r, C, f);
+            const bool gbc = gb_uses_f16c(h, r, C), cvc = main_uses_f16c(h, r, C, f), cv6 = main_uses_f16c6(h, r, C, f);
             const int hslots = gb8 ? fp8_pad(128) / 4 : 128, aslots = cv8 ? fp8_pad(C) / 4 : C;
             snprintf(k, sizeof k, "ws.gen.rb%d.h%d", i, j); int rc2 = alloc_padded(h, k, r, hslots, &hb); if (rc2) return rc2;
             snprintf(k, sizeof k, "ws.gen.rb%d.a%d", i, j); rc2 = alloc_padded(h, k, r, aslots, &ab); if (rc2) return rc2;
@@ -952,7 +1011,7 @@ int plan_spade(msr_handle* h) {
                 gb.conv.wt_frag = 0;
             }
             if (cv8) gb.conv.out_split = 3;           // its epilogue writes bf8 bytes for the fp8 consumer
-            if (cvc) gb.conv.out_split = 4;           // ... the f16c chunk image for the f16c consumer
+            if (cvc) gb.conv.out_split = cv6 ? 5 : 4; // ... the f16c (fp8 pieces) / f16c6 (fp6 pieces) chunk image for the consumer
             set_out_padded(gb.conv, ab);
             set_aux_dense(gb.conv, x, rx, C, xshift);
             gb.conv.mean = mean; gb.conv.stdv = stdv;
@@ -971,7 +1030,13 @@ int plan_spade(msr_handle* h) {
                 cv.conv.ksplit = 1;
                 cv.conv.wt_frag = 0;
             }
-            if (cvc) {
+            if (cv6) {
+                cv.conv.prec = PREC_F16C6;                    // the weight image carries its scales
+                cv.conv.wexp = nullptr;
+                cv.tile = TILE_256x128_PP;
+                cv.conv.ksplit = 1;
+                cv.conv.wt_frag = 0;
+            } else if (cvc) {
                 snprintf(k, sizeof k, "gen.rb%d.conv_%d.kernel.wexp", i, conv_idx);
                 cv.conv.prec = PREC_F16C;
                 cv.conv.wexp = reinterpret_cast<const int*>(need(k));
@@ -1483,10 +1548,13 @@ int msr_op_conv3x3_f16c(msr_handle* h, const float* in_dev, const float* wt_dev,
                         int32_t epilogue, const float* aux_dev, int32_t aux_shift, const float* mean_dev,
                         const float* std_dev, int32_t out_padded, int32_t out_mode, void* stream) {
     if (!h) return MSR_ERR_INVALID;
-    if (!in_dev || !wt_dev || !wexp_dev || !bias_dev || !out_dev || B < 1 || rout < 16 || Cin % 64 || N % 128)
+    if (!in_dev || !wt_dev || !bias_dev || !out_dev || B < 1 || rout < 16 || Cin % 64 || N % 128)
         return fail(h, MSR_ERR_INVALID, "msr_op_conv3x3_f16c: bad argument (Cin %% 64, N %% 128, rout >= 16)");
+    // wexp_dev == nullptr: the operands are f16c6 images (fp6 pieces, scales inside; stream kernel, bias / residual epilogues)
+    if (!wexp_dev && (epilogue == EPI_SPADE || Cin % 128))
+        return fail(h, MSR_ERR_INVALID, "msr_op_conv3x3_f16c: the f16c6 form takes the bias / residual epilogues and Cin %% 128 == 0");
     if (epilogue < EPI_BIAS || epilogue > EPI_SPADE || (epilogue != EPI_BIAS && !aux_dev) ||
-        (epilogue == EPI_SPADE && (!mean_dev || !std_dev)) || (out_mode != 0 && out_mode != 1 && out_mode != 4) ||
+        (epilogue == EPI_SPADE && (!mean_dev || !std_dev)) || (out_mode != 0 && out_mode != 1 && out_mode != 4 && out_mode != 5) ||
         (out_mode != 0 && epilogue != EPI_SPADE))
         return fail(h, MSR_ERR_INVALID, "msr_op_conv3x3_f16c: bad epilogue / output mode");
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -1495,7 +1563,7 @@ int msr_op_conv3x3_f16c(msr_handle* h, const float* in_dev, const float* wt_dev,
     op.tile = TILE_256x128_PP;
     op.conv.ksplit = 1;
     op.conv.wt_frag = 0;
-    op.conv.prec = PREC_F16C;
+    op.conv.prec = wexp_dev ? PREC_F16C : PREC_F16C6;
     op.conv.wexp = wexp_dev;
     op.conv.out_split = epilogue == EPI_SPADE ? out_mode : 0;
     const int Cout = epilogue == EPI_SPADE ? N / 2 : N;

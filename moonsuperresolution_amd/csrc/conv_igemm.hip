@@ -412,6 +412,10 @@ __device__ __forceinline__ void halo16_epilogue_body(const ConvParams& p, f32x4 
 // "epilogue store tail").  Here the wave writes the pieces of one tile row (16 pixels x 32 channels = 16 chunk lines) into
 // a private 2.3 KB LDS image, reads each line back as two 16-byte quarters per lane and issues TWO stores per row, each
 // 64 contiguous bytes per pixel.  Private to the wave (LDS operations of one wave execute in order): no barrier.
+// F6 = true writes the PREC_F16C6 image (kernels.h): the block scale of a pixel's 32 channels needs the maximum over the four
+// lanes that share the pixel (16 lanes apart) — they exchange it through the four pad dwords of the pixel's staged line — and
+// the 6-bit codes of a lane's four channels are three bytes of the line, written as bytes.
+template <bool F6>
 __device__ __forceinline__ void halo16_epilogue_spade_f16c_staged(const ConvParams& p, f32x4 (&acc)[4][4], int wm, int wn,
                                                                   int lane, int n0, int tx0, int ty0, int b0,
                                                                   float4 (&xin)[4][2], float4 (&cv)[8], unsigned* stage) {
@@ -427,32 +431,67 @@ __device__ __forceinline__ void halo16_epilogue_spade_f16c_staged(const ConvPara
     for (int jj = 0; jj < 2; ++jj) {
         rs[jj][0] = 1.f / cv[6 + jj].x; rs[jj][1] = 1.f / cv[6 + jj].y; rs[jj][2] = 1.f / cv[6 + jj].z; rs[jj][3] = 1.f / cv[6 + jj].w;
     }
+    if constexpr (F6) {     // the zero bytes behind the two scale bytes of a line (dwords 23 and 31) never change
+        if (cg == 0) { line[23] = 0u; line[31] = 0u; }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+        float v[2][4];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const float gq[4] = {cv[jj].x, cv[jj].y, cv[jj].z, cv[jj].w};
             const float bq[4] = {cv[2 + jj].x, cv[2 + jj].y, cv[2 + jj].z, cv[2 + jj].w};
             const float mq[4] = {cv[4 + jj].x, cv[4 + jj].y, cv[4 + jj].z, cv[4 + jj].w};
             const float xq[4] = {xin[i][jj].x, xin[i][jj].y, xin[i][jj].z, xin[i][jj].w};
-            float v[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float normalized = (xq[k] - mq[k]) * rs[jj][k];
                 const float t = (acc[i][jj][k] + gq[k]) * normalized + (acc[i][jj + 2][k] + bq[k]);
-                v[k] = t >= 0.f ? t : t * p.slope;
-                v[k] = v[k] > 65504.f ? 65504.f : (v[k] < -65504.f ? -65504.f : v[k]);     // as msr_store_f16c4_dev
+                float u = t >= 0.f ? t : t * p.slope;
+                v[jj][k] = u > 65504.f ? 65504.f : (u < -65504.f ? -65504.f : u);           // as msr_store_f16c4_dev
             }
-            const h2 a = {(_Float16)v[0], (_Float16)v[1]}, b = {(_Float16)v[2], (_Float16)v[3]};
-            unsigned h8 = 0, l8 = 0;
-            h8 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], h8, false);
-            h8 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], h8, true);
-            l8 = __builtin_amdgcn_cvt_pk_fp8_f32((v[0] - (float)a[0]) * 2048.f, (v[1] - (float)a[1]) * 2048.f, l8, false);
-            l8 = __builtin_amdgcn_cvt_pk_fp8_f32((v[2] - (float)b[0]) * 2048.f, (v[3] - (float)b[1]) * 2048.f, l8, true);
-            // the chunk image of the pixel: dwords 0..15 fp16 pairs, 16..23 h8, 24..31 l8 (channel 16 jj + 4 cg + {0..3})
+        }
+        float inv = 1.f;        // F6: 2^-E of the pixel's block scale
+        if constexpr (F6) {
+            float m = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m = fmaxf(m, fabsf(v[jj][k]));       // NaN: dropped here, kept in the fp16 piece
+            line[32 + cg] = __builtin_bit_cast(unsigned, m);
+            asm volatile("" ::: "memory");
+            const uint4 mm = *reinterpret_cast<const uint4*>(line + 32);
+            asm volatile("" ::: "memory");
+            const float amax = fmaxf(fmaxf(__builtin_bit_cast(float, mm.x), __builtin_bit_cast(float, mm.y)),
+                                     fmaxf(__builtin_bit_cast(float, mm.z), __builtin_bit_cast(float, mm.w)));
+            const int eb = msr_block_e8m0_dev(amax);
+            inv = __builtin_bit_cast(float, (254 - eb) << 23);                   // 2^-(eb - 127)
+            if (cg == 0) line[22] = (unsigned)eb;                                // byte 88: the h6 piece's e8m0
+            if (cg == 1) line[30] = (unsigned)(eb - 11);                         // byte 120: the l6 piece's
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const h2 a = {(_Float16)v[jj][0], (_Float16)v[jj][1]}, b = {(_Float16)v[jj][2], (_Float16)v[jj][3]};
+            const float l0 = (v[jj][0] - (float)a[0]) * 2048.f, l1 = (v[jj][1] - (float)a[1]) * 2048.f;
+            const float l2 = (v[jj][2] - (float)b[0]) * 2048.f, l3 = (v[jj][3] - (float)b[1]) * 2048.f;
+            // the chunk image of the pixel: dwords 0..15 fp16 pairs (channel 16 jj + 4 cg + {0..3})
             *reinterpret_cast<uint2*>(line + jj * 8 + 2 * cg) = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
-            line[16 + jj * 4 + cg] = h8;
-            line[24 + jj * 4 + cg] = l8;
+            if constexpr (F6) {
+                // 4 codes = 24 bits = bytes 64 + 3 * (4 jj + cg) .. of the line (l6: 96 + ...)
+                const unsigned h6 = msr_pack_e2m3x4_dev(v[jj][0] * inv, v[jj][1] * inv, v[jj][2] * inv, v[jj][3] * inv);
+                const unsigned l6 = msr_pack_e2m3x4_dev(l0 * inv, l1 * inv, l2 * inv, l3 * inv);
+                unsigned char* lb = reinterpret_cast<unsigned char*>(line) + 3 * (4 * jj + cg);
+                lb[64] = (unsigned char)h6; lb[65] = (unsigned char)(h6 >> 8); lb[66] = (unsigned char)(h6 >> 16);
+                lb[96] = (unsigned char)l6; lb[97] = (unsigned char)(l6 >> 8); lb[98] = (unsigned char)(l6 >> 16);
+            } else {
+                unsigned h8 = 0, l8 = 0;
+                h8 = __builtin_amdgcn_cvt_pk_fp8_f32(v[jj][0], v[jj][1], h8, false);
+                h8 = __builtin_amdgcn_cvt_pk_fp8_f32(v[jj][2], v[jj][3], h8, true);
+                l8 = __builtin_amdgcn_cvt_pk_fp8_f32(l0, l1, l8, false);
+                l8 = __builtin_amdgcn_cvt_pk_fp8_f32(l2, l3, l8, true);
+                line[16 + jj * 4 + cg] = h8;                   // dwords 16..23 h8, 24..31 l8
+                line[24 + jj * 4 + cg] = l8;
+            }
         }
         // quarter cg of each half of the line (compiler barriers: the pieces were written through other types)
         asm volatile("" ::: "memory");
@@ -471,7 +510,8 @@ __device__ __forceinline__ void halo16_epilogue(const ConvParams& p, const TileG
                                                 float4 (&cv)[8], unsigned* stage = nullptr) {
     const int stat_tile = (b0 * g.tiles_y + (ty0 >> g.th_l)) * g.tiles_x + (tx0 >> g.tw_l);
     if constexpr (EPI == EPI_SPADE) {
-        if (p.out_split == 4 && stage) halo16_epilogue_spade_f16c_staged(p, acc, wm, wn, lane, n0, tx0, ty0, b0, xin, cv, stage);
+        if (p.out_split == 5 && stage) halo16_epilogue_spade_f16c_staged<true>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, xin, cv, stage);
+        else if (p.out_split == 4 && stage) halo16_epilogue_spade_f16c_staged<false>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, xin, cv, stage);
         else if (p.out_split == 4) halo16_epilogue_body<EPI, true, false, true>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile, xin, cv);
         else if (p.out_split == 3) halo16_epilogue_body<EPI, true, true>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile, xin, cv);
         else if (p.out_split) halo16_epilogue_body<EPI, true>(p, acc, wm, wn, lane, n0, tx0, ty0, b0, stat_tile, xin, cv);
@@ -2073,6 +2113,7 @@ static hipError_t launch_pp(const ConvParams& p, int epi, hipStream_t s) {
 }
 
 hipError_t launch_conv_igemm(const ConvParams& p, int epilogue, int tile, hipStream_t s) {
+    if (p.prec == PREC_F16C6) return tile == TILE_256x128_PP ? launch_conv_f16c_sw(p, epilogue, s) : hipErrorInvalidValue;
     if (p.prec == PREC_F16X2 || p.prec == PREC_FP8 || p.prec == PREC_F16C)
         return tile == TILE_256x128_PP ? launch_pp(p, epilogue, s) : hipErrorInvalidValue;
     if (p.prec == PREC_BF16X3) {

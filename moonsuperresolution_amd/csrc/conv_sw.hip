@@ -188,7 +188,11 @@ __device__ __forceinline__ void sw_epilogue(const ConvParams& p, const SwGeom& g
 #define SW_PDC 3
 #endif
 
-template <int EPI>
+// F6 = true: PREC_F16C6 operands (kernels.h): the cross terms run on fp6 e2m3 pieces, 16 instead of 32 matrix-pipe cycles
+// per K = 128 MFMA.  A lane then reads ONE 32-byte half of ONE tap's chunk row (the even tap's for lane groups 0 / 1, the odd
+// tap's for 2 / 3; first / second half for even / odd groups): the same two 16-byte loads as before, the operand in the
+// first six registers, the block scale in byte 0 of the seventh.
+template <int EPI, bool F6 = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 conv_igemm_f16c_sw(const ConvParams p, const SwGeom g) {
     constexpr int HW = SW_HW, HP = SW_HP, BKP = SW_BKP, HPB = SW_HPB;
@@ -242,10 +246,15 @@ conv_igemm_f16c_sw(const ConvParams p, const SwGeom g) {
 #define SW_HGOFF(q) ((((SW_HPIX(q) * 3641) >> 16) * p.in_py + (SW_HPIX(q) - ((SW_HPIX(q) * 3641) >> 16) * HW) * p.Cin + hseg * 4) * 4)
 #define SW_HLOFF(q) ((q) < 10 ? h_l0 + 32 * (q) * BKP : SW_HPIX(q) * BKP + hseg * 4)
     // weight rows of the wave: column block j -> rows 64 * (wq >> 1) + 16 * (wq & 1) + 32 * j + (lane & 15)
-    int b_voff[2];
+    int b_voff[2], b_xoff[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) b_voff[j] = (((wq >> 1) * 64 + (wq & 1) * 16 + 32 * j + px) * p.Cin) * 4 + 16 * cg;
+    for (int j = 0; j < 2; ++j) {
+        const int row_ = (((wq >> 1) * 64 + (wq & 1) * 16 + 32 * j + px) * p.Cin) * 4;
+        b_voff[j] = row_ + 16 * cg;
+        b_xoff[j] = F6 ? row_ + 64 + 32 * (cg & 1) : row_ + 16 * cg + 64;     // the cross piece(s) of the lane
+    }
     const int a_lane = px * BKP + 4 * cg;                               // float offset of the lane inside a fragment row
+    const int x_lane = px * BKP + 16 + 8 * (cg & 1);                    // F6: the lane's 32-byte half of a chunk row
 
     const unsigned w_tap_bytes = (unsigned)((size_t)p.N * p.Cin * sizeof(float));
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
@@ -273,15 +282,31 @@ conv_igemm_f16c_sw(const ConvParams p, const SwGeom g) {
 #define SW_LOAD_B(dstE, dstO, dxE, dxO, T, j)                                                    \
     {                                                                                            \
         dstE[j] = SW_BUFLD(rs_wt, b_voff[j], SW_WSOFF(T));                                       \
-        dxE[j] = SW_BUFLD(rs_wt, b_voff[j] + 64, SW_WSOFF(T));                                   \
         dstO[j] = SW_BUFLD(rs_wt, b_voff[j], SW_WSOFF((T) + 1));                                 \
-        dxO[j] = SW_BUFLD(rs_wt, b_voff[j] + 64, SW_WSOFF((T) + 1));                             \
+        if constexpr (F6) {                                                                      \
+            /* both 16-byte halves of the lane's piece, from the even tap's row (lane groups 0, 1) or the odd tap's (2, 3); \
+               the scalar offset is the smaller of the two taps' (the other one's excess rides in the lane offset) */ \
+            const unsigned lo_ = min(SW_WSOFF(T), SW_WSOFF((T) + 1));                            \
+            const int dv_ = (int)((cg < 2 ? SW_WSOFF(T) : SW_WSOFF((T) + 1)) - lo_);             \
+            dxE[j] = SW_BUFLD(rs_wt, b_xoff[j] + dv_, lo_);                                      \
+            dxO[j] = SW_BUFLD(rs_wt, b_xoff[j] + dv_ + 16, lo_);                                 \
+        } else {                                                                                 \
+            dxE[j] = SW_BUFLD(rs_wt, b_xoff[j], SW_WSOFF(T));                                    \
+            dxO[j] = SW_BUFLD(rs_wt, b_xoff[j], SW_WSOFF((T) + 1));                              \
+        }                                                                                        \
     }
     // pixel fragment i of K-step T (T = 18.. : the next body's first chunk)
 #define SW_APTR(T) ((T) < 9 ? A0 : (T) < 18 ? A1 : A2)
 #define SW_AOFF(T, i) ((((i) + (((T) % 9) / 3)) * HW + (((T) % 9) % 3)) * BKP)
 #define SW_RD_F(dst, T, i) dst = *reinterpret_cast<const i32x4*>(SW_APTR(T) + SW_AOFF(T, i))
 #define SW_RD_X(dst, T, i) dst = *reinterpret_cast<const i32x4*>(SW_APTR(T) + SW_AOFF(T, i) + 16)
+    // F6: the lane's chunk-row half of pixel fragment i of tap pair (TE, TE + 1): XP = per-lane pointer of that pair (below)
+#define SW_XP(TE) ((cg < 2 ? SW_APTR(TE) + SW_AOFF(TE, 0) : SW_APTR((TE) + 1) + SW_AOFF((TE) + 1, 0)) - a_lane + x_lane)
+#define SW_RD_X6(dlo, dhi, XP, i)                                                                \
+    {                                                                                            \
+        dlo = *reinterpret_cast<const i32x4*>((XP) + (i) * HW * BKP);                            \
+        dhi = *reinterpret_cast<const i32x4*>((XP) + (i) * HW * BKP + 4);                        \
+    }
 #define SW_F16(v) __builtin_bit_cast(f16x8, v)
 #define SW_CAT8(lo, hi) __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)
     // halo staging of K-step T: chunk (T / 9) + 1 of the body (chunk 2 = whatever comes after the pair) travels while
@@ -339,11 +364,16 @@ conv_igemm_f16c_sw(const ConvParams p, const SwGeom g) {
         constexpr int T = 2 * (U) + 1;                                                           \
         SW_STAMP(2)                                                                              \
         SW_HALO(T)                                                                               \
+        const float* const xp_ = SW_XP(T - 1);                                                   \
         _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                         \
             if (i + PD < 16) SW_RD_F(fb[(i + PD) & 15], T, (i + PD) & 15);                       \
             if (i >= 16 - PDC) {                                                                 \
-                SW_RD_X(ce[(i + PDC) & 15], T - 1, (i + PDC) & 15);                              \
-                SW_RD_X(co[(i + PDC) & 15], T, (i + PDC) & 15);                                  \
+                if constexpr (F6) {                                                              \
+                    SW_RD_X6(ce[(i + PDC) & 15], co[(i + PDC) & 15], xp_, (i + PDC) & 15)        \
+                } else {                                                                         \
+                    SW_RD_X(ce[(i + PDC) & 15], T - 1, (i + PDC) & 15);                          \
+                    SW_RD_X(co[(i + PDC) & 15], T, (i + PDC) & 15);                              \
+                }                                                                                \
             }                                                                                    \
             acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(SW_F16(bO[0]), SW_F16(fb[i]), acc[i][0], 0, 0, 0); \
             acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(SW_F16(bO[1]), SW_F16(fb[i]), acc[i][1], 0, 0, 0); \
@@ -357,16 +387,26 @@ conv_igemm_f16c_sw(const ConvParams p, const SwGeom g) {
         constexpr int T = 2 * (U);                                                               \
         SW_STAMP(2)                                                                              \
         const i32x8 wq0_ = SW_CAT8(xE[0], xO[0]), wq1_ = SW_CAT8(xE[1], xO[1]);                  \
+        const float* const xp_ = SW_XP(T);                                                       \
         _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                         \
             if (T + 2 == 18 && i == 16 - PD) SW_BARRIER()                                        \
             if (i + PDC < 16) {                                                                  \
-                SW_RD_X(ce[(i + PDC) & 15], T, (i + PDC) & 15);                                  \
-                SW_RD_X(co[(i + PDC) & 15], T + 1, (i + PDC) & 15);                              \
+                if constexpr (F6) {                                                              \
+                    SW_RD_X6(ce[(i + PDC) & 15], co[(i + PDC) & 15], xp_, (i + PDC) & 15)        \
+                } else {                                                                         \
+                    SW_RD_X(ce[(i + PDC) & 15], T, (i + PDC) & 15);                              \
+                    SW_RD_X(co[(i + PDC) & 15], T + 1, (i + PDC) & 15);                          \
+                }                                                                                \
             }                                                                                    \
             if (i >= 16 - PD) SW_RD_F(fa[(i + PD) & 15], T + 2, (i + PD) & 15);                  \
             const i32x8 aq_ = SW_CAT8(ce[i], co[i]);                                             \
-            acc[i][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wq0_, aq_, acc[i][0], 0, 0, 0, wsc[0], 0, asc); \
-            acc[i][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wq1_, aq_, acc[i][1], 0, 0, 0, wsc[1], 0, asc); \
+            if constexpr (F6) {     /* fp6 x fp6: operands in registers 0..5, the block scales in byte 0 of register 6 */ \
+                acc[i][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wq0_, aq_, acc[i][0], 2, 2, 0, wq0_[6], 0, aq_[6]); \
+                acc[i][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wq1_, aq_, acc[i][1], 2, 2, 0, wq1_[6], 0, aq_[6]); \
+            } else {                                                                             \
+                acc[i][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wq0_, aq_, acc[i][0], 0, 0, 0, wsc[0], 0, asc); \
+                acc[i][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wq1_, aq_, acc[i][1], 0, 0, 0, wsc[1], 0, asc); \
+            }                                                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                   \
         }                                                                                        \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) { bE[j] = nbE[j]; bO[j] = nbO[j]; xE[j] = nxE[j]; xO[j] = nxO[j]; } \
@@ -423,7 +463,7 @@ conv_igemm_f16c_sw(const ConvParams p, const SwGeom g) {
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {       // byte 0 = e8m0 of the channel's w_lo pieces (even lane groups), byte 1 = of its w_hi pieces
-            const int w_ = p.wexp[n0 + (wq >> 1) * 64 + (wq & 1) * 16 + 32 * j + px];
+            const int w_ = F6 ? 0 : p.wexp[n0 + (wq >> 1) * 64 + (wq & 1) * 16 + 32 * j + px];      // F6: the scales ride in the image
             wsc[j] = (((cg & 1) ? (w_ >> 8) : w_) & 0xFF) * 0x01010101;
         }
 #if SW_UNROLL2   // two bodies per iteration (Cin % 128 == 0): halves the cost of the allocator's accumulator rotation
@@ -479,6 +519,8 @@ conv_igemm_f16c_sw(const ConvParams p, const SwGeom g) {
 #undef SW_AOFF
 #undef SW_RD_F
 #undef SW_RD_X
+#undef SW_XP
+#undef SW_RD_X6
 #undef SW_F16
 #undef SW_CAT8
 #undef SW_HALO
@@ -498,6 +540,10 @@ hipError_t conv_sw_init() {
         return e;
     SW_SET(EPI_BIAS) SW_SET(EPI_RES) SW_SET(EPI_SPADE)
 #undef SW_SET
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f16c_sw<EPI_BIAS, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)SW_LDS)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f16c_sw<EPI_RES, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)SW_LDS)) != hipSuccess) return e;
     return hipSuccess;
 }
 
@@ -506,7 +552,9 @@ hipError_t conv_sw_init() {
 hipError_t launch_conv_f16c_sw(const ConvParams& p, int epi, hipStream_t s) {
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
     if (epi == EPI_SPADE && p.out_split != 0 && p.out_split != 1 && p.out_split != 4) return hipErrorInvalidValue;
-    if (p.prec != PREC_F16C || !p.wexp || p.ksplit > 1 || p.stride != 1 || p.KH != 3 || p.KW != 3) return hipErrorInvalidValue;
+    const bool f6 = p.prec == PREC_F16C6;
+    if ((p.prec != PREC_F16C && !f6) || (!f6 && !p.wexp) || p.ksplit > 1 || p.stride != 1 || p.KH != 3 || p.KW != 3) return hipErrorInvalidValue;
+    if (f6 && epi == EPI_SPADE) return hipErrorInvalidValue;          // the fp6 form exists for the main convs
     if (!pow2(p.Hout) || !pow2(p.Wout) || p.Hout < 16 || p.Wout < 16 || p.N % 128 || p.Cin % (SW_UNROLL2 ? 128 : 64)) return hipErrorInvalidValue;
     if ((size_t)p.B * p.in_pb * sizeof(float) >= ((size_t)1 << 31)) return hipErrorInvalidValue;   // buffer descriptor range
     SwGeom g;
@@ -523,6 +571,11 @@ hipError_t launch_conv_f16c_sw(const ConvParams& p, int epi, hipStream_t s) {
         if (n_cu < 8) n_cu = 8;
     }
     const int grid = g.tiles_mn < n_cu ? ((g.tiles_mn + 7) & ~7) : n_cu;
+    if (f6) {
+        if (epi == EPI_BIAS) conv_igemm_f16c_sw<EPI_BIAS, true><<<grid, 256, SW_LDS, s>>>(p, g);
+        else conv_igemm_f16c_sw<EPI_RES, true><<<grid, 256, SW_LDS, s>>>(p, g);
+        return hipGetLastError();
+    }
     switch (epi) {
         case EPI_BIAS: conv_igemm_f16c_sw<EPI_BIAS><<<grid, 256, SW_LDS, s>>>(p, g); break;
         case EPI_RES: conv_igemm_f16c_sw<EPI_RES><<<grid, 256, SW_LDS, s>>>(p, g); break;

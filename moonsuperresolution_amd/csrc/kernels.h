@@ -81,7 +81,22 @@ struct ConvParams {
 // w_lo * x_hi, w_hi * x_lo) with a power-of-two scale per output channel and kind (ConvParams.wexp: byte 0 = e8m0 of the
 // lo bytes, byte 1 = of the hi bytes).  Operand map of v_mfma_scale_f32_16x16x128_f8f6f4 as measured: lane (row, g)'s 32
 // bytes are k = 16g..16g+15 and 64+16g..64+16g+15; the e8m0 scale of k-block b (32 consecutive k) comes from lane group b.
-enum ConvPrecision : int { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_F16X2 = 2, PREC_FP8 = 3, PREC_F16C = 4 };
+// PREC_F16C6: PREC_F16C with the cross terms in fp6 e2m3 — the block-scaled MFMA runs fp6 operands at twice its fp8 rate, so a
+// product costs 1.5 MFMA-equivalents instead of 2, at the same end-to-end accuracy (e2m3 has e4m3's three mantissa bits;
+// tests/emulate_cross_formats.py: 5.6e-5 against 5.9e-5).  e2m3 spans only six binades, so the pieces carry a block scale:
+// one power of two per pixel and 32-channel chunk for activations (2^E >= max|x| / 7.5; the lo piece uses 2^(E-11)), one
+// per output channel and piece for weights.  Chunk image (128 bytes per 32 channels):
+//   bytes   0.. 63  32 x hi f16
+//   bytes  64.. 87  32 x 6-bit codes, little-endian bit string (channel c at bits 6c..6c+5): activations h6 = e2m3(x / 2^E),
+//                   weights l6 = e2m3((w - hi) / 2^El)
+//   byte   88       e8m0 of that piece's scale (127 + E, resp. 127 + El); bytes 89..95 zero
+//   bytes  96..119  the other piece: activations l6 = e2m3((x - hi) / 2^(E-11)), weights h6 = e2m3(w / 2^Eh)
+//   byte  120       its e8m0 (127 + E - 11, resp. 127 + Eh); bytes 121..127 zero
+// so that a lane reads ONE 32-byte half (two 16-byte loads) and holds the MFMA's 6-register operand in the first six
+// registers and its scale in byte 0 of the seventh.  Operand map of the instruction for fp6 (tests/gpu_diag_fp6.hip,
+// profiles/r02_mfma_scale_operand_map.txt): lane group g's 32 elements are one k-block whose scale comes from lane group g;
+// here g = 0 / 1 hold the first / second half of the EVEN tap's chunk row, g = 2 / 3 of the odd tap's.
+enum ConvPrecision : int { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_F16X2 = 2, PREC_FP8 = 3, PREC_F16C = 4, PREC_F16C6 = 5 };
 
 __host__ __device__ inline unsigned msr_bf16_rn(float v) {   // round-to-nearest-even, finite inputs
     union { float f; unsigned u; } c;
@@ -157,6 +172,41 @@ inline unsigned char msr_f32_to_e4m3(float v) {
     if (e > 8 || (e == 8 && r > 14.f)) return sign | 0x7E;
     if (r < 8.f) return sign | (unsigned char)r;             // subnormal: exponent field 0, mantissa r
     return sign | (unsigned char)(((e + 7) << 3) | ((int)r - 8));
+}
+
+// fp32 -> fp6 e2m3 code (sign | 2 exponent bits, bias 1 | 3 mantissa bits; max 7.5, subnormal step 1/8), round to nearest even,
+// saturating; host side of the PREC_F16C6 weight upload
+inline unsigned msr_f32_to_e2m3(float v) {
+    const unsigned sign = v < 0.f ? 0x20u : 0u;
+    float a = v < 0.f ? -v : v;
+    if (!(a == a)) return sign | 0x1F;
+    if (a >= 7.5f) return sign | 0x1F;
+    if (a < 1.f) return sign | (unsigned)__builtin_nearbyintf(a * 8.f);       // subnormals (and 1.0 = code 8 by carry)
+    int e;
+    (void)__builtin_frexpf(a, &e);                                             // a = m * 2^e, m in [0.5, 1)
+    e -= 1;                                                                    // a = 1.m * 2^e, e in 0..2
+    float r = __builtin_nearbyintf(__builtin_ldexpf(a, 3 - e));                // 8..16
+    if (r >= 16.f) { r = 8.f; e += 1; }
+    if (e > 2) return sign | 0x1F;
+    return sign | (unsigned)(((e + 1) << 3) | ((int)r - 8));
+}
+
+// Device: four values already divided by the block scale (|q| <= 7.5) -> their four e2m3 codes packed in 24 bits.  The
+// hardware converter does the rounding: e4m3 of q * 2^-6 has the same three mantissa bits and subnormal grid, and its
+// exponent field stays below 4, so the code is the e4m3 byte's low five bits plus the sign.
+__device__ inline unsigned msr_pack_e2m3x4_dev(float q0, float q1, float q2, float q3) {
+    unsigned c8 = 0;
+    c8 = __builtin_amdgcn_cvt_pk_fp8_f32(q0 * 0.015625f, q1 * 0.015625f, c8, false);
+    c8 = __builtin_amdgcn_cvt_pk_fp8_f32(q2 * 0.015625f, q3 * 0.015625f, c8, true);
+    const unsigned six = (c8 & 0x1F1F1F1Fu) | ((c8 >> 2) & 0x20202020u);
+    return (six & 0x3Fu) | ((six >> 2) & 0xFC0u) | ((six >> 4) & 0x3F000u) | ((six >> 6) & 0xFC0000u);
+}
+// e8m0 byte of the block scale 2^E >= amax / 7.5 (E = ceil(log2(amax / 7.5)), clamped; amax = 0 -> 2^0)
+__device__ inline int msr_block_e8m0_dev(float amax) {
+    const int bits = __builtin_bit_cast(int, amax * (1.f / 7.5f)) + 0x7FFFFF;   // a non-zero mantissa carries into the exponent
+    int eb = (bits >> 23) & 0xFF;
+    eb = amax > 0.f ? eb : 127;
+    return eb < 27 ? 27 : (eb > 247 ? 247 : eb);
 }
 
 // Device: 4 consecutive channels c..c+3 (c % 4 == 0) of one pixel into the pixel's f16c chunk image (PREC_F16C above).

@@ -223,18 +223,116 @@ def f16c_weight_image(w_kl: torch.Tensor):
     return _f16c_pack(hi, l8, h8), wexp.contiguous(), (hi.double(), h8.double() * sh.double(), l8.double() * sl.double())
 
 
+# ---- f16c6: fp16 main term + fp6 e2m3 cross pieces with block scales (csrc/kernels.h PREC_F16C6) ------------------------------
+_E2M3 = torch.tensor([i / 8 for i in range(8)] + [1 + i / 8 for i in range(8)] + [2 + i / 4 for i in range(8)] +
+                     [4 + i / 2 for i in range(8)], dtype=torch.float64)
+
+
+def _e2m3_codes(q: torch.Tensor) -> torch.Tensor:
+    """|q| <= 7.5 (float64) -> 6-bit codes (uint8), round to nearest (ties to the even code, as the hardware converter)."""
+    grid = _E2M3.to(q.device)
+    a = q.abs().clamp(max=7.5)
+    idx = torch.bucketize(a, (grid[1:] + grid[:-1]) / 2, right=False)
+    # a tie sits exactly on a midpoint: bucketize(right=False) puts it in the lower bucket; RNE wants the even code
+    mid = (grid[1:] + grid[:-1]) / 2
+    tie = (idx < 31) & (a == mid[idx.clamp(max=30)])
+    idx = torch.where(tie & (idx % 2 == 1), idx + 1, idx)
+    return (idx.to(torch.uint8) | ((q < 0) & (a > 0)).to(torch.uint8) * 32).to(torch.uint8)
+
+
+def _pack6(codes: torch.Tensor) -> torch.Tensor:
+    """[..., 32] 6-bit codes -> [..., 24] bytes, little-endian bit string (element c at bits 6c..6c+5)."""
+    c = codes.to(torch.int64).reshape(codes.shape[:-1] + (8, 4))
+    w = c[..., 0] | (c[..., 1] << 6) | (c[..., 2] << 12) | (c[..., 3] << 18)       # 24 bits per 4 codes
+    b = torch.stack([w & 255, (w >> 8) & 255, (w >> 16) & 255], dim=-1)
+    return b.reshape(codes.shape[:-1] + (24,)).to(torch.uint8)
+
+
+def _f16c6_pack(hi: torch.Tensor, first: torch.Tensor, e_first: torch.Tensor, second: torch.Tensor, e_second: torch.Tensor):
+    """hi [..., C] fp16, the two code pieces [..., C] and their e8m0 bytes [..., C // 32] -> float32 storage [..., C]."""
+    shp = hi.shape
+    n = shp[-1] // 32
+    out = torch.zeros(shp[:-1] + (n, 128), dtype=torch.uint8, device=hi.device)
+    out[..., 0:64] = hi.contiguous().view(torch.uint8).reshape(shp[:-1] + (n, 64))
+    out[..., 64:88] = _pack6(first.reshape(shp[:-1] + (n, 32)))
+    out[..., 88] = e_first.to(torch.uint8)
+    out[..., 96:120] = _pack6(second.reshape(shp[:-1] + (n, 32)))
+    out[..., 120] = e_second.to(torch.uint8)
+    return out.reshape(shp[:-1] + (n * 128,)).view(torch.float32).reshape(shp)
+
+
+def _ceil_log2_over(amax: torch.Tensor, top: float) -> torch.Tensor:
+    """E = ceil(log2(amax / top)) as int64 (0 where amax == 0)"""
+    m, e = torch.frexp((amax.double() / top))
+    E = torch.where(m == 0.5, e - 1, e).to(torch.int64)
+    return torch.where(amax > 0, E, torch.zeros_like(E))
+
+
+def f16c6_activation_image(x: torch.Tensor):
+    """fp32 [..., C] -> (f16c6 image, (hi, h6, l6) de-quantised float64 parts): one scale 2^E >= max|x| / 7.5 per pixel and
+    32-channel chunk, h6 = e2m3(x / 2^E), l6 = e2m3((x - hi) / 2^(E - 11)) — what the SPADE epilogue writes."""
+    shp = x.shape
+    n = shp[-1] // 32
+    hi = x.to(torch.float16)
+    lo = (x - hi.float()).double()
+    xb = x.double().reshape(shp[:-1] + (n, 32))
+    E = _ceil_log2_over(xb.abs().amax(-1), 7.5).clamp(-100, 120)
+    s = torch.pow(2.0, E.double())[..., None]
+    ch = _e2m3_codes(xb / s)
+    cl = _e2m3_codes(lo.reshape(xb.shape) / (s / 2048.0))
+    dec = lambda c: torch.where(c >= 32, -_E2M3.to(c.device)[(c & 31).long()], _E2M3.to(c.device)[(c & 31).long()])   # noqa: E731
+    img = _f16c6_pack(hi, ch, 127 + E, cl, 127 + E - 11)
+    return img, (hi.double(), (dec(ch) * s).reshape(shp), (dec(cl) * s / 2048.0).reshape(shp))
+
+
+def f16c6_weight_image(w_kl: torch.Tensor):
+    """Kernel-layout weights [taps][N][Cin] -> (f16c6 image, (hi, h6, l6) de-quantised): one scale per output channel and piece;
+    the lo piece is stored first so that half g of a weight row pairs with half g of an activation row."""
+    hi = w_kl.to(torch.float16)
+    lo = (w_kl - hi.float()).double()
+    Eh = _ceil_log2_over(w_kl.abs().amax(dim=(0, 2)), 7.5).clamp(-100, 100)
+    El = _ceil_log2_over(lo.abs().amax(dim=(0, 2)), 7.5).clamp(-100, 100)
+    sh = torch.pow(2.0, Eh.double())[None, :, None]
+    sl = torch.pow(2.0, El.double())[None, :, None]
+    ch, cl = _e2m3_codes(w_kl.double() / sh), _e2m3_codes(lo / sl)
+    n = w_kl.shape[-1] // 32
+    eb = lambda E: (127 + E)[None, :, None].expand(w_kl.shape[0], -1, n)   # noqa: E731
+    dec = lambda c: torch.where(c >= 32, -_E2M3.to(c.device)[(c & 31).long()], _E2M3.to(c.device)[(c & 31).long()])   # noqa: E731
+    img = _f16c6_pack(hi, cl, eb(El), ch, eb(Eh))
+    return img, (hi.double(), dec(ch) * sh, dec(cl) * sl)
+
+
+def f16c6_decode(img: torch.Tensor):
+    """f16c6 activation image -> (hi, h6, l6) float64 tensors [..., C] (pieces multiplied by their block scales)."""
+    shp = img.shape
+    n = shp[-1] // 32
+    b = img.contiguous().view(torch.uint8).reshape(shp[:-1] + (n, 128)).long()
+    hi = img.contiguous().view(torch.uint8).reshape(shp[:-1] + (n, 128))[..., 0:64].contiguous().view(torch.float16).reshape(shp).double()
+
+    def piece(off):
+        by = b[..., off:off + 24].reshape(shp[:-1] + (n, 8, 3))
+        w = by[..., 0] | (by[..., 1] << 8) | (by[..., 2] << 16)
+        c = torch.stack([(w >> (6 * k)) & 63 for k in range(4)], dim=-1).reshape(shp[:-1] + (n, 32))
+        grid = _E2M3.to(img.device)
+        v = torch.where(c >= 32, -grid[c & 31], grid[c & 31])
+        s = torch.pow(2.0, (b[..., off + 24] - 127).double())[..., None]
+        return (v * s).reshape(shp)
+    return hi, piece(64), piece(96)
+
+
 def conv3x3_f16c(ctx: OpContext, x_img: torch.Tensor, w_img: torch.Tensor, wexp: torch.Tensor, bias: torch.Tensor, rout: int,
                  epilogue: int = EPI_BIAS, aux: Optional[torch.Tensor] = None, aux_shift: int = 0,
                  mean: Optional[torch.Tensor] = None, std: Optional[torch.Tensor] = None, out_padded: bool = False,
                  out_mode: int = 0) -> torch.Tensor:
-    """One launch of the f16c form of the persistent ping-pong conv (msr_op_conv3x3_f16c)."""
+    """One launch of the f16c conv (msr_op_conv3x3_f16c; the library sends it to the ping-pong or the stream kernel).
+    ``wexp=None``: the operands are f16c6 images (fp6 pieces, stream kernel)."""
     B, Cin = x_img.shape[0], x_img.shape[3]
     N = w_img.shape[1]
     Cout = N // 2 if epilogue == EPI_SPADE else N
     shape = (B, rout + 2, rout + 2, Cout) if out_padded else (B, rout, rout, Cout)
     out = torch.zeros(shape, dtype=torch.float32, device=x_img.device)
     p = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
-    rc = ctx.lib.msr_op_conv3x3_f16c(ctx.h, x_img.data_ptr(), w_img.data_ptr(), wexp.data_ptr(), bias.data_ptr(),
+    rc = ctx.lib.msr_op_conv3x3_f16c(ctx.h, x_img.data_ptr(), w_img.data_ptr(), p(wexp), bias.data_ptr(),
                                      out.data_ptr(), B, rout, Cin, N, epilogue, p(aux), aux_shift, p(mean), p(std),
                                      1 if out_padded else 0, out_mode, torch.cuda.current_stream(x_img.device).cuda_stream)
     _lib.raise_for(ctx.lib, ctx.h, rc, "msr_op_conv3x3_f16c")

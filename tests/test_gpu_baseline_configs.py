@@ -91,7 +91,8 @@ def test_baseline_config_matches_oracle(hip_lib, S, B, precision):
     e_std = rel_linf(gen.debug_tensor("ws.gen.rb5.std1", (256,)), s_ref)
     e_rb4 = rel_linf(gen.debug_tensor("ws.gen.rb4.out", (B, r4, r4, 512)), cap["gen.rb4.out"])
     e_z = rel_linf(gen.last_latent(), cap["z"])
-    _record(S=S, B=B, precision=precision, oracle=oracle_dtype, rel_linf_output=err, rel_linf_rb5_x1=e_x1,
+    _record(S=S, B=B, precision=precision + ("+fp6 main-conv cross pieces (MSR_F16C_FP6=1)" if os.environ.get("MSR_F16C_FP6") == "1" else ""),
+            oracle=oracle_dtype, rel_linf_output=err, rel_linf_rb5_x1=e_x1,
             rb5_mean1=e_mean, rb5_std1=e_std, rel_linf_rb4_out=e_rb4, rel_linf_z=e_z)
     gen.close()
     del gen
@@ -99,6 +100,18 @@ def test_baseline_config_matches_oracle(hip_lib, S, B, precision):
     assert y.shape == (B, S, S, 1) and np.isfinite(y).all()
     assert err <= TOL, err
     assert max(e_x1, e_rb4, e_z, e_mean, e_std) <= TOL, (e_x1, e_rb4, e_z, e_mean, e_std)
+
+
+def test_f16c_with_the_opt_in_fp6_cross_pieces_matches_oracle():
+    """MSR_F16C_FP6=1 (read once per process): the stream-kernel main convs take fp6 e2m3 cross pieces with block scales
+    (kernels.h PREC_F16C6), written by the gamma|beta convs' epilogues.  Same bar; the BASELINE shapes run in a child process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MSR_F16C_FP6="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "test_baseline_config_matches_oracle and f16c and (256-16 or 512-8)"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("precision", ["f16c", "bf16x3", "fp32"])

@@ -358,6 +358,74 @@ def test_conv_f16c_spade_epilogue_writes_the_chunk_image(ctx):
     assert float(full[0][:, 0].abs().max()) == 0 and float(full[1][:, :, -1].abs().max()) == 0     # the border stays zero
 
 
+@pytest.mark.parametrize("B,r,cin,cout,res", [(1, 32, 256, 256, False), (3, 64, 128, 128, True), (9, 32, 128, 512, False)])
+def test_conv_f16c6(ctx, B, r, cin, cout, res):
+    """fp16 main term + fp6 e2m3 cross pieces with block scales (PREC_F16C6, the stream kernel): exact up to accumulation
+    against the float64 evaluation of its own three terms on the de-quantised operands (pins the 6-bit packing, the 32-byte
+    half a lane reads, the pairing of halves and taps in the 128-deep MFMA and the scales read from the images), and 2e-4
+    against the float64 conv of the original operands."""
+    from moonsuperresolution_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(61 + B + r)
+    x = (torch.randn((B, r, r, cin), generator=g) * torch.logspace(-1.5, 0.5, cin)).cuda()
+    w = (torch.randn((3, 3, cin, cout), generator=g) / np.sqrt(9 * cin) * torch.logspace(-2, 1, cout)).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    skip = torch.randn((B, r, r, cout), generator=g).cuda() if res else None
+    ximg, (xh, x6, xl) = ops.f16c6_activation_image(ops.pad_nhwc(x))
+    wimg, (wh, w6, wl) = ops.f16c6_weight_image(ops.kernel_layout(w))
+    y = ops.conv3x3_f16c(ctx, ximg, wimg, None, b, r, epilogue=ops.EPI_RES if res else ops.EPI_BIAS, aux=skip).cpu().numpy()
+    hwio = lambda t: t.cpu().permute(0, 2, 1).reshape(3, 3, cin, cout)     # noqa: E731
+    zero = torch.zeros(cout, dtype=torch.float64)
+    cut = lambda t: t[:, 1:-1, 1:-1].cpu()                                 # noqa: E731
+    emu = ref_conv(cut(xh), hwio(wh), b, 1) + ref_conv(cut(x6), hwio(wl), zero, 1) + ref_conv(cut(xl), hwio(w6), zero, 1)
+    true = ref_conv(x, w, b, 1)
+    if res:
+        emu = emu + skip.double().cpu()
+        true = true + skip.double().cpu()
+    e_emu, e_true = rel_linf(y, emu.numpy()), rel_linf(y, true.numpy())
+    print("f16c6 conv: vs its own three terms in fp64", e_emu, " vs the fp64 conv", e_true)
+    assert e_emu <= 5e-5, e_emu
+    assert e_true <= 2e-4, e_true
+
+
+def test_conv_f16c_spade_epilogue_writes_the_f16c6_image(ctx):
+    """The ping-pong kernel's LDS-assembled SPADE epilogue with out_mode 5: hi = f16_rn(v); the block scale of a pixel's 32
+    channels is the smallest power of two >= max|v| / 7.5; h6 / l6 are e2m3 of v and of v - hi on that scale."""
+    from moonsuperresolution_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(59)
+    B, r, C, shift = 3, 32, 128, 1
+    h = torch.relu(torch.randn((B, r, r, 128), generator=g)).cuda()
+    wg = (torch.randn((3, 3, 128, C), generator=g) / 34).cuda()
+    wb_ = (torch.randn((3, 3, 128, C), generator=g) / 34).cuda()
+    bg, bb = torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+    x = (3 + 2 * torch.randn((B, r >> shift, r >> shift, C), generator=g)).cuda()
+    mean = x.mean((0, 1, 2)).contiguous()
+    std = torch.sqrt(x.var((0, 1, 2), unbiased=False) + 1e-5).contiguous()
+    w, bias = ops.spade_layout(wg, wb_, bg, bb)
+    himg, _ = ops.f16c_activation_image(ops.pad_nhwc(h))
+    wimg, wexp, _ = ops.f16c_weight_image(w)
+    kw = dict(epilogue=ops.EPI_SPADE, aux=x, aux_shift=shift, mean=mean, std=std, out_padded=True)
+    y32 = ops.conv3x3_f16c(ctx, himg, wimg, wexp, bias, r, out_mode=0, **kw)
+    y6 = ops.conv3x3_f16c(ctx, himg, wimg, wexp, bias, r, out_mode=5, **kw)
+    want = y32[:, 1:-1, 1:-1].contiguous()
+    ref_img, (rhi, rh6, rl6) = ops.f16c6_activation_image(want)
+    hi, h6, l6 = (t[:, 1:-1, 1:-1] for t in ops.f16c6_decode(y6))
+    # (the fp32 run divides by sigma where the packed one multiplies by 1 / sigma: the two agree to an ulp, not bit for bit)
+    scale = float(want.abs().max())
+    assert float((hi - want.double()).abs().max()) <= 2.0 ** -11 * scale               # hi is the fp16 rounding of the value
+    blk = want.double().abs().reshape(B, r, r, C // 32, 32).amax(-1, keepdim=True).expand(B, r, r, C // 32, 32).reshape(want.shape)
+    assert float(((h6 - want.double()).abs() / blk).max()) <= 0.07                     # e2m3 on the block scale
+    assert float(((hi + l6 - want.double()).abs() / blk).max()) <= 2.0 ** -13
+    # the device picks the scales of the host restatement (a block whose max / 7.5 sits within an ulp of a power of two may
+    # land one binade off: allow 1 %), and the second piece's scale is the first one's / 2^11
+    got = y6[:, 1:-1, 1:-1].contiguous().view(torch.uint8).reshape(-1, 128)
+    ref = ref_img.contiguous().view(torch.uint8).reshape(-1, 128)
+    assert int((got[:, 88] != ref[:, 88]).sum()) <= got.shape[0] // 100
+    assert torch.equal(got[:, 88].int() - 11, got[:, 120].int())
+    assert int(got[:, 89:96].abs().max()) == 0 and int(got[:, 121:128].abs().max()) == 0
+    full = ops.f16c6_decode(y6)
+    assert float(full[0][:, 0].abs().max()) == 0 and float(full[1][:, :, -1].abs().max()) == 0     # the border stays zero
+
+
 @pytest.mark.parametrize("mode", ["0", "2"])
 def test_f16c_convs_under_the_other_kernel_dispatch(mode):
     """PREC_F16C launches go to the stream kernel (conv_sw.hip) for the bias / residual epilogues and to the ping-pong kernel
