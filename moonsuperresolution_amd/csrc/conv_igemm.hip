@@ -2075,7 +2075,9 @@ static hipError_t launch_pp(const ConvParams& p, int epi, hipStream_t s) {
         // conv_sw.hip (one software-pipelined wave per SIMD) takes the long-K main convs; the gamma|beta convs stay here, where
         // a second wave on the SIMD hides their SPADE epilogue.  MSR_F16C_SW = 0: everything here, 2: everything there (A/B).
         static const int sw_mode = std::getenv("MSR_F16C_SW") ? std::atoi(std::getenv("MSR_F16C_SW")) : 1;
-        if (p.Cin % 128 == 0 && (sw_mode == 2 || (sw_mode == 1 && epi != EPI_SPADE))) return launch_conv_f16c_sw(p, epi, s);
+        if (p.Cin % 128 == 0 && !(epi == EPI_SPADE && p.out_split == 5) &&     // (the fp6 image is written by this kernel's epilogue only)
+            (sw_mode == 2 || (sw_mode == 1 && epi != EPI_SPADE)))
+            return launch_conv_f16c_sw(p, epi, s);
         switch (epi) {
             case EPI_BIAS: conv_igemm_bf16x3_pp<EPI_BIAS, PP_F16C><<<grid, 512, PP_LDS, s>>>(p, g); break;
             case EPI_RES: conv_igemm_bf16x3_pp<EPI_RES, PP_F16C><<<grid, 512, PP_LDS, s>>>(p, g); break;
