@@ -112,3 +112,33 @@ def test_e4m3_quantiser_matches_torch():
     got_f = torch.from_numpy(out).view(torch.float8_e4m3fn).float().numpy()
     ref_f = torch.from_numpy(ref).view(torch.float8_e4m3fn).float().numpy()
     assert np.array_equal(got_f, ref_f)              # compare values: +0 and -0 are the same weight
+
+
+def test_f16c6_image_helpers_round_trip_on_cpu():
+    """The host restatement of the f16c6 chunk image (csrc/kernels.h PREC_F16C6: fp16 main piece + two e2m3 pieces with a
+    power-of-two scale per 32-channel block): decode(pack(x)) returns the pieces bit for bit, the block scale is the
+    smallest power of two >= max|x| / 7.5, h6 carries e2m3's 3 mantissa bits on that scale and hi + l6 recovers x to ~2^-15."""
+    import torch
+    from moonsuperresolution_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((2, 3, 5, 96), generator=g) * torch.logspace(-3, 1, 96)
+    x[0, 0, 0, :32] = 0.0                                   # an all-zero block: scale 2^0, codes 0
+    img, (hi, h6, l6) = ops.f16c6_activation_image(x)
+    assert img.shape == x.shape and img.dtype == torch.float32
+    d_hi, d_h6, d_l6 = ops.f16c6_decode(img)
+    assert torch.equal(d_hi, hi) and torch.equal(d_h6, h6) and torch.equal(d_l6, l6)
+    raw = img.contiguous().view(torch.uint8).reshape(-1, 128)
+    amax = x.double().abs().reshape(-1, 32).amax(-1)
+    E = raw[:, 88].double() - 127
+    nz = amax > 0
+    assert bool((2.0 ** E[nz] >= amax[nz] / 7.5).all()) and bool((2.0 ** (E[nz] - 1) < amax[nz] / 7.5).all())
+    assert bool((raw[~nz][:, 88] == 127).all()) and bool((raw[:, 120].int() == raw[:, 88].int() - 11).all())
+    assert int(raw[:, 89:96].max()) == 0 and int(raw[:, 121:128].max()) == 0
+    blk = amax.reshape(x.shape[:-1] + (3, 1)).expand(x.shape[:-1] + (3, 32)).reshape(x.shape).clamp_min(1e-30)
+    assert float(((h6 - x.double()).abs() / blk).max()) <= 1 / 15 + 1e-9            # half an e2m3 step of the top binade
+    assert float(((hi + l6 - x.double()).abs() / blk).max()) <= 2.0 ** -14
+    w = torch.randn((9, 64, 64), generator=g) * 0.05
+    wimg, (wh, w6, wl) = ops.f16c6_weight_image(w)
+    wraw = wimg.contiguous().view(torch.uint8).reshape(9, 64, 2, 128)
+    assert bool((wraw[..., 88] == wraw[0, :, 0, 88][None, :, None]).all())           # one scale per output channel and piece
+    assert float((wh + wl - w.double()).abs().max()) <= 2.0 ** -14 * float(w.abs().max())
