@@ -91,10 +91,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # as bench.py: MSR_BENCH_BACKEND=gloo (+ MSR_BENCH_DEVICE) rehearses the N-rank path on a one-GPU box
+    backend = os.environ.get("MSR_BENCH_BACKEND", "nccl")
+    if "MSR_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["MSR_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     S, s, B, T = args.image_size, args.stride, args.batch_size, args.tile_size
     t_setup = time.perf_counter()
