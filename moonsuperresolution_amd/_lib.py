@@ -108,18 +108,25 @@ def is_stale() -> bool:
 
 def build(verbose: bool = False, force: bool = False) -> str:
     """Compile libmoonsr_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    if force or is_stale():
-        for f in os.listdir(CSRC):          # objects of an older source state: make only compares file times
-            if f.endswith(".o") and force:
-                os.remove(os.path.join(CSRC, f))
+    if not (force or is_stale()):
+        return LIB_PATH                     # the stamp says the .so was built from exactly these sources
+    # Stale (or forced): file times do not survive a snapshot, so `make` alone could decide that objects of an OLDER
+    # source state are up to date and the stamp below would then bless them.  Rebuild every object unconditionally.
+    for f in os.listdir(CSRC):
+        if f.endswith(".o") or f == os.path.basename(LIB_PATH):
+            os.remove(os.path.join(CSRC, f))
+    if os.path.exists(STAMP_PATH):
+        os.remove(STAMP_PATH)
+    want = sources_hash()
     res = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
     if verbose or res.returncode:
         print(res.stdout[-4000:])
         print(res.stderr[-4000:])
-    if res.returncode:
+    if res.returncode or not os.path.exists(LIB_PATH):
         raise RuntimeError("building libmoonsr_hip.so failed (see output above)")
-    with open(STAMP_PATH, "w") as fh:
-        fh.write(sources_hash() + "\n")
+    if sources_hash() == want:              # sources edited during the build: leave the tree marked stale
+        with open(STAMP_PATH, "w") as fh:
+            fh.write(want + "\n")
     return LIB_PATH
 
 

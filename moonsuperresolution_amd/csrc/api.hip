@@ -543,6 +543,11 @@ int msr_create(const msr_config* cfg, msr_handle** out) {
         return fail(nullptr, MSR_ERR_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only",
                     cfg->device, prop.gcnArchName);
     if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, MSR_ERR_DEVICE, "hipSetDevice failed");
+#ifdef MSR_DIAG_BUILD   // stamp / what-if object (kernels.h): never the product
+    if (!(std::getenv("MSR_ALLOW_DIAG_BUILD") && std::atoi(std::getenv("MSR_ALLOW_DIAG_BUILD")) == 1))
+        return fail(nullptr, MSR_ERR_STATE, "this libmoonsr_hip.so is a diagnostic build (-DMSR_DIAG_BUILD: in-kernel stamps "
+                    "or what-if switches that change results); set MSR_ALLOW_DIAG_BUILD=1 to use it for measurements");
+#endif
     if (conv_igemm_init() != hipSuccess)
         return fail(nullptr, MSR_ERR_DEVICE, "could not set the dynamic-LDS attribute of the conv kernels");
     auto h = std::make_unique<msr_handle>();

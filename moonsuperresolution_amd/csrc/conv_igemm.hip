@@ -407,7 +407,7 @@ __device__ __forceinline__ void halo16_epilogue_body(const ConvParams& p, f32x4 
 
 // EPI_SPADE writing the f16c chunk image, assembled per pixel in LDS.  A lane's 4 channels are three pieces of the pixel's
 // 128-byte chunk (8 bytes of fp16, 4 of h8, 4 of l8): stored straight from the lane that is SIX store instructions per tile
-// row, each touching 16 lines with 4- or 8-byte pieces, and the epilogue is store-ISSUE-bound (tests/gpu_pp_stamps_gb.py: a
+// row, each touching 16 lines with 4- or 8-byte pieces, and the epilogue is store-ISSUE-bound (tools/gpu_pp_stamps_gb.py: a
 // gamma|beta tile takes 87.4k cycles, 79.4k with one 16-byte store per lane, 77.4k with none; MI355X_MICROARCH.md
 // "epilogue store tail").  Here the wave writes the pieces of one tile row (16 pixels x 32 channels = 16 chunk lines) into
 // a private 2.3 KB LDS image, reads each line back as two 16-byte quarters per lane and issues TWO stores per row, each
@@ -1478,7 +1478,7 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0); \
         }                                                                                        \
     }
-// Diagnostic build only (-DMSR_PP_STAMPS, tests/gpu_pp_stamps.py): s_memtime stamps of waves 0 (X) and 4 (Y) of one
+// Diagnostic build only (-DMSR_PP_STAMPS, tools/gpu_pp_stamps.py): s_memtime stamps of waves 0 (X) and 4 (Y) of one
 // workgroup around the segments of one chunk pair, kept in the LDS words behind the product's 144,640 bytes.
 #ifdef MSR_PP_STAMPS
 #define MSR_STAMP()                                                                              \
@@ -1595,7 +1595,7 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
         // its R(0) of the next tile), Y right after its last M, BEFORE that barrier.  (Each group used to run it after the
         // barrier: X's epilogue then faced only Y's last M and Y's only X's first M of the next tile, i.e. the two
         // epilogues — ~10k cycles each with their loads and stores — ran one after the other: a gamma|beta tile took 87k
-        // cycles for 58k of K loop, tests/gpu_pp_stamps_gb.py.)  Its stores are not waited for.
+        // cycles for 58k of K loop, tools/gpu_pp_stamps_gb.py.)  Its stores are not waited for.
         // PP_FP8: the scaled MFMA does not accumulate in place under register pressure, so its epilogue operands are
         // not held across the last K-steps but requested here
         if constexpr (ONE) {       // the body's second item
@@ -1910,7 +1910,7 @@ hipError_t launch_moments_from_slabs(const float* partial, int P, int C, float e
 
 int conv_pick_tile(int M, int N, int epilogue, int prec, int ksteps) {
     // The big tile needs >= ~2 waves of workgroups per CU to hide its barrier; otherwise take the small one.
-    // Measured on MI355X (tests/gpu_conv_bench.py): the 16-channel K-step (3 workgroups per CU) is ~8 % faster
+    // Measured on MI355X (tools/gpu_conv_bench.py): the 16-channel K-step (3 workgroups per CU) is ~8 % faster
     // than the 32-channel one for the SPADE epilogue (its long epilogue is covered by a third resident
     // workgroup) and ~3 % slower for plain long-K convs.
     // At bf16 rates the 128 x 128 tile is 1.6x as efficient as the 64 x 64 one, so one workgroup per CU is enough.
@@ -1919,7 +1919,7 @@ int conv_pick_tile(int M, int N, int epilogue, int prec, int ksteps) {
         return (epilogue == EPI_SPADE && prec == PREC_F32) ? TILE_128x128_K16 : TILE_128x128;
     // Few pixels, long K (the r <= 8 main convs, r = 16 at small batch): these layers stream their weights, and the
     // 128-row tile reads each weight for twice as many pixels; split-K (>= 72 K-steps) supplies the workgroups.
-    // tests/gpu_smalltile_sweep.py: 93 -> 70 us (B=16, r=8, 1024 -> 1024), 171 -> 120 us (B=8, r=16).
+    // tools/gpu_smalltile_sweep.py: 93 -> 70 us (B=16, r=8, 1024 -> 1024), 171 -> 120 us (B=8, r=16).
     if (prec == PREC_BF16X3 && N % 128 == 0 && M >= 128 && ksteps >= 72 && big_blocks * 16 >= 256) return TILE_128x128;
     return TILE_64x64;
 }
@@ -1931,7 +1931,7 @@ int conv_pick_ksplit(int M, int N, int ksteps, int tile, int prec) {
     const long blocks = (long)((M + bm - 1) / bm) * (N / bm);
     long want = tile == TILE_64x64 ? 1024 : 512;
     // short K at bf16 rates (the gamma/beta convs, 36 K-steps): the split-K pass costs more than it buys beyond one
-    // workgroup per CU (tests/gpu_smalltile_sweep.py: 28 vs 33 us at B=16, r=8)
+    // workgroup per CU (tools/gpu_smalltile_sweep.py: 28 vs 33 us at B=16, r=8)
     if (prec == PREC_BF16X3 && ksteps < 72) want = 256;
     int ks = 1;
     while (blocks * ks < want && ks < 16 && ksteps / (ks * 2) >= 4) ks *= 2;

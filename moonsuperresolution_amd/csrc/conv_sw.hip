@@ -7,7 +7,7 @@
 // phase lasts max(memory segment ~560 cycles, matrix segment) + a barrier turn-around, and the f16c arithmetic (256 /
 // 768 MFMA cycles on even / odd steps) leaves the matrix pipe ~64 % busy.  Here a workgroup is FOUR waves, one per SIMD,
 // each with the whole 512-entry register file, and every wave runs MFMAs back to back with its own loads issued in the
-// gaps (measured: 78 % busy, tests/gpu_sw_stamps.py — at a clock the chip lowers to ~1.75 GHz from the ping-pong kernel's
+// gaps (measured: 78 % busy, tools/gpu_sw_stamps.py — at a clock the chip lowers to ~1.75 GHz from the ping-pong kernel's
 // ~1.94, which is why the layer-level gain is 3-5 % and not 20 %):
 //   * wave q owns ALL 256 pixels of the tile and 32 of its 128 output columns (two 16-column blocks): 16 x 2
 //     accumulator tiles of 16 x 16 = 128 registers.  Its weights are nobody else's, so they go global -> registers
@@ -25,7 +25,7 @@
 //   write of chunk n+1 (taps 3..8 of chunk n) -> buffer (n+1) % 3, last read in phase C of the pair straddling n-2 | n-1,
 //   which every wave has left before B(n); first read of it after B(n+1).
 // What one wave per SIMD cannot do is hide an epilogue: VALU instructions between its MFMAs cost their full issue time
-// (4 fillers per K = 128 MFMA pair: +12 %, tests/gpu_sw_bench.py history in DESIGN.md), and the SPADE epilogue (a quarter of
+// (4 fillers per K = 128 MFMA pair: +12 %, tools/gpu_sw_bench.py history in DESIGN.md), and the SPADE epilogue (a quarter of
 // a gamma|beta layer when exposed) is hidden only by a second wave on the SIMD.  So the planner keeps the gamma|beta convs
 // on the ping-pong kernel and gives this one the long-K main convs, whose epilogue is 1-2 % of a tile.
 #include "kernels.h"
@@ -328,7 +328,7 @@ conv_igemm_f16c_sw(const ConvParams p, const SwGeom g) {
             if constexpr (2 * t_ + 1 < H_ITEMS) rh[t_ % HD][1] = SW_BUFLD(rs_in, SW_HGOFF((2 * t_ + 1) % H_ITEMS), hs_); \
         }                                                                                        \
     }
-    // Diagnostic build only (-DMSR_SW_STAMPS=1: one s_memtime stamp per tap pair, =2: per phase; tests/gpu_sw_stamps.py):
+    // Diagnostic build only (-DMSR_SW_STAMPS=1: one s_memtime stamp per tap pair, =2: per phase; tools/gpu_sw_stamps.py):
     // lane 0 of every wave of workgroup 8 stamps one body of its first tile into the LDS words behind the halo ring.
     // (A stamp waits for lgkmcnt(0): level 2 slows the stream down by a third.)
 #ifdef MSR_SW_STAMPS

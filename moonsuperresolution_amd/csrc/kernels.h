@@ -4,6 +4,17 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
+// Diagnostic switches (in-kernel s_memtime stamps; what-if builds that compute WRONG results on purpose to price one
+// cost: SW_NOBAR, SW_NOEPI, MSR_WI_ONESTORE, MSR_WI_NOSTORE) compile only into a library that declares itself a
+// diagnostic build: -DMSR_DIAG_BUILD.  msr_create of such a library fails unless MSR_ALLOW_DIAG_BUILD=1 is set, so a
+// what-if object can never be picked up as the product by accident (tools/gpu_*_stamps.py, tools/gpu_ab.sh set it).
+#if defined(SW_NOBAR) || defined(SW_NOEPI) || defined(MSR_WI_ONESTORE) || defined(MSR_WI_NOSTORE) || \
+    defined(MSR_SW_STAMPS) || defined(MSR_PP_STAMPS) || defined(MSR_GB_STAMPS)
+#ifndef MSR_DIAG_BUILD
+#error "stamp / what-if switches need -DMSR_DIAG_BUILD (msr_create then refuses the library unless MSR_ALLOW_DIAG_BUILD=1)"
+#endif
+#endif
+
 namespace msr {
 
 // ---------------------------------------------------------------------------------------------
@@ -83,7 +94,7 @@ struct ConvParams {
 // bytes are k = 16g..16g+15 and 64+16g..64+16g+15; the e8m0 scale of k-block b (32 consecutive k) comes from lane group b.
 // PREC_F16C6: PREC_F16C with the cross terms in fp6 e2m3 — the block-scaled MFMA runs fp6 operands at twice its fp8 rate, so a
 // product costs 1.5 MFMA-equivalents instead of 2, at the same end-to-end accuracy (e2m3 has e4m3's three mantissa bits;
-// tests/emulate_cross_formats.py: 5.6e-5 against 5.9e-5).  e2m3 spans only six binades, so the pieces carry a block scale:
+// tools/emulate_cross_formats.py: 5.6e-5 against 5.9e-5).  e2m3 spans only six binades, so the pieces carry a block scale:
 // one power of two per pixel and 32-channel chunk for activations (2^E >= max|x| / 7.5; the lo piece uses 2^(E-11)), one
 // per output channel and piece for weights.  Chunk image (128 bytes per 32 channels):
 //   bytes   0.. 63  32 x hi f16
@@ -93,7 +104,7 @@ struct ConvParams {
 //   bytes  96..119  the other piece: activations l6 = e2m3((x - hi) / 2^(E-11)), weights h6 = e2m3(w / 2^Eh)
 //   byte  120       its e8m0 (127 + E - 11, resp. 127 + Eh); bytes 121..127 zero
 // so that a lane reads ONE 32-byte half (two 16-byte loads) and holds the MFMA's 6-register operand in the first six
-// registers and its scale in byte 0 of the seventh.  Operand map of the instruction for fp6 (tests/gpu_diag_fp6.hip,
+// registers and its scale in byte 0 of the seventh.  Operand map of the instruction for fp6 (tools/gpu_diag_fp6.hip,
 // profiles/r02_mfma_scale_operand_map.txt): lane group g's 32 elements are one k-block whose scale comes from lane group g;
 // here g = 0 / 1 hold the first / second half of the EVEN tap's chunk row, g = 2 / 3 of the odd tap's.
 enum ConvPrecision : int { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_F16X2 = 2, PREC_FP8 = 3, PREC_F16C = 4, PREC_F16C6 = 5 };

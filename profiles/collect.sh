@@ -32,8 +32,8 @@ python bench.py --streams 2 --no-cpu-baseline > $O/bench_spade256_bf16x3_2stream
 python bench.py --workload spade512 > $O/bench_spade512_bf16x3.json 2> $O/bench_spade512_bf16x3.err || exit 1
 python bench.py --precision fp32 --steps 20 > $O/bench_spade256_fp32.json 2> $O/bench_spade256_fp32.err || exit 1
 echo "bench done"
-python tests/gpu_latency.py > $O/latency.txt 2>&1 || exit 1
-python tests/gpu_p2p_latency.py > $O/p2p_latency.txt 2>&1 || exit 1
+python tools/gpu_latency.py > $O/latency.txt 2>&1 || exit 1
+python tools/gpu_p2p_latency.py > $O/p2p_latency.txt 2>&1 || exit 1
 python raster_bench.py > $O/raster.txt 2>&1 || exit 1
 python raster_bench.py --image-size 512 --stride 64 --batch-size 8 > $O/raster512.txt 2>&1 || exit 1
 echo "all done"

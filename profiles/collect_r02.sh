@@ -47,5 +47,5 @@ rocprofv3 --kernel-trace --stats -d $O/kt_raster -o kt --output-format csv -- py
 python profiles/trace_families.py $O/kt_raster/kt_kernel_trace.csv tiles > $O/raster512_families.txt || exit 1
 python raster_bench.py > $O/raster256.json 2> /dev/null || exit 1
 python raster_bench.py --image-size 512 --stride 64 --batch-size 8 > $O/raster512.json 2> /dev/null || exit 1
-(python tests/gpu_determinism_soak.py 512 8 200 && python tests/gpu_determinism_soak.py 256 16 300) > $O/determinism_soak.txt 2>&1 || exit 1
+(python tools/gpu_determinism_soak.py 512 8 200 && python tools/gpu_determinism_soak.py 256 16 300) > $O/determinism_soak.txt 2>&1 || exit 1
 echo "all done"

@@ -1,7 +1,7 @@
 """Diagnostic (not a pytest, CPU only): end-to-end error of the f16c arithmetic with the cross terms in fp8 e4m3 (the mode
 that ships), fp6 e2m3 or fp4 e2m1 (block-scaled: one power-of-two scale per pixel and 32-channel chunk for activations, per
 output channel and piece for weights), emulated inside the float64 oracle on every 3 x 3 stride-1 conv with Cin >= 128 (a
-superset of the layers the GPU path covers).   usage: python tests/emulate_cross_formats.py [S] [B]"""
+superset of the layers the GPU path covers).   usage: python tools/emulate_cross_formats.py [S] [B]"""
 import sys
 import numpy as np
 import torch

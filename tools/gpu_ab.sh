@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of two builds of libmoonsr_hip.so on ONE box (boxes differ by ~5 %): alternates bench.py runs.
-# usage: tests/gpu_ab.sh <libA.so> <libB.so> [rounds] [extra bench args]
+# usage: tools/gpu_ab.sh <libA.so> <libB.so> [rounds] [extra bench args]
 A=$1; B=$2; R=${3:-2}; shift 3
 for i in $(seq 1 $R); do
   for v in A B; do

@@ -1,5 +1,5 @@
 """Micro-benchmark of conv_igemm_f32 on the generator's layer shapes (not a pytest).
-usage: python tests/gpu_conv_bench.py [S B [name-filter]]  -> TFLOP/s per layer shape, both tiles"""
+usage: python tools/gpu_conv_bench.py [S B [name-filter]]  -> TFLOP/s per layer shape, both tiles"""
 import sys
 import torch
 sys.path.insert(0, ".")

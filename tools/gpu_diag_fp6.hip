@@ -1,6 +1,6 @@
 // Diagnostic (not a test): operand / scale map of v_mfma_scale_f32_16x16x128_f8f6f4 with fp6 e2m3 (or fp4 e2m1) operands on
 // gfx950.  One wave, random operand bits; the host evaluates the product under candidate maps and reports which one the
-// hardware follows.   hipcc --offload-arch=gfx950 -O2 tests/gpu_diag_fp6.hip -o build/diag_fp6 && build/diag_fp6
+// hardware follows.   hipcc --offload-arch=gfx950 -O2 tools/gpu_diag_fp6.hip -o build/diag_fp6 && build/diag_fp6
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

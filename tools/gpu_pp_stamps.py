@@ -2,8 +2,8 @@
 per-step segment durations (R, barrier, M, barrier) of waves 0 (X) and 4 (Y) of one workgroup in shader-clock cycles.
 
     cp -r moonsuperresolution_amd/csrc /tmp/csrc_stamps && cp -r include /tmp/include   # keeps the product objects clean
-    make -C /tmp/csrc_stamps clean all EXTRA=-DMSR_PP_STAMPS        # (the Makefile reads ../../include: copy the tree)
-    MSR_LIB=/path/to/stamped/libmoonsr_hip.so python tests/gpu_pp_stamps.py
+    make -C /tmp/csrc_stamps clean all EXTRA="-DMSR_DIAG_BUILD -DMSR_PP_STAMPS"       # (the Makefile reads ../../include: copy the tree)
+    MSR_ALLOW_DIAG_BUILD=1 MSR_LIB=/path/to/stamped/libmoonsr_hip.so python tools/gpu_pp_stamps.py
 """
 import sys
 import torch

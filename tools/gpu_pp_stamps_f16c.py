@@ -1,5 +1,5 @@
 """Diagnostic (not a pytest): per-step segment durations of the f16c form of the ping-pong conv (stamped build, see
-tests/gpu_pp_stamps.py for the build recipe)."""
+tools/gpu_pp_stamps.py for the build recipe)."""
 import sys
 import torch
 sys.path.insert(0, ".")

@@ -1,6 +1,6 @@
 """Diagnostic (not a pytest): per-tile cycle counts of the ping-pong kernel on a gamma|beta layer shape (stamped build, see
-tests/gpu_pp_stamps.py for the recipe; run with MSR_F16C_SW=0).  36 K-steps per tile: compare with 36 x the per-step figure
-of the long-K layers (tests/gpu_pp_stamps_f16c.py)."""
+tools/gpu_pp_stamps.py for the recipe; run with MSR_F16C_SW=0).  36 K-steps per tile: compare with 36 x the per-step figure
+of the long-K layers (tools/gpu_pp_stamps_f16c.py)."""
 import sys
 import torch
 sys.path.insert(0, ".")

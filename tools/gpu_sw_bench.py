@@ -1,5 +1,5 @@
 """Diagnostic (not a pytest): kernel-level A/B of the f16c conv forms on two BASELINE layer shapes.
-    rocprofv3 --kernel-trace --stats ... -- python3 tests/gpu_sw_bench.py      (MSR_F16C_SW=0: the ping-pong kernel, 2: the stream kernel for both)
+    rocprofv3 --kernel-trace --stats ... -- python3 tools/gpu_sw_bench.py      (MSR_F16C_SW=0: the ping-pong kernel, 2: the stream kernel for both)
 main = rb4.conv1 of SPADE-512 B=8 (r 64, 1024 -> 512, bias epilogue);  gb = rb5.gb1 (r 128, 128 -> 2 x 512, SPADE epilogue)."""
 import sys
 import time

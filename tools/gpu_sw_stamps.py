@@ -1,8 +1,8 @@
 """Diagnostic (not a pytest): in-kernel s_memtime stamps of the software-pipelined f16c conv (conv_sw.hip).
 
     cp -r moonsuperresolution_amd/csrc /tmp/csrc_stamps && cp -r include /tmp/include
-    make -C /tmp/csrc_stamps clean all EXTRA=-DMSR_SW_STAMPS=1     # =2: one stamp per phase (E, O, C) instead of per tap pair
-    MSR_LIB=/tmp/csrc_stamps/libmoonsr_hip.so python tests/gpu_sw_stamps.py [main|gb]
+    make -C /tmp/csrc_stamps clean all EXTRA="-DMSR_DIAG_BUILD -DMSR_SW_STAMPS=1"    # =2: one stamp per phase (E, O, C) instead of per tap pair
+    MSR_ALLOW_DIAG_BUILD=1 MSR_LIB=/tmp/csrc_stamps/libmoonsr_hip.so python tools/gpu_sw_stamps.py [main|gb]
 Ideal (MFMA cycles only): 2048 per tap pair = 512 (E) + 512 (O) + 1024 (C); 18432 per body of 18 K-steps."""
 import sys
 import torch

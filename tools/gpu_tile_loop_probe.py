@@ -1,5 +1,5 @@
 """Probe (not a pytest): which ingredient of the tile loop costs throughput with two generator streams.
-usage: python tests/gpu_tile_loop_probe.py [S B stride]"""
+usage: python tools/gpu_tile_loop_probe.py [S B stride]"""
 import os
 import sys
 import time
