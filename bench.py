@@ -342,31 +342,31 @@ def run_workload(args, D: Dist, workload: str, precision: str, with_cpu: bool, w
         g1 = Generator(S, 1, variant="gaugan", weights=weights, eps=eps[:1], device=local, precision=precision)
         x1 = torch.from_numpy(synthetic_patches(1, S, seed=5)).cuda()
         o1 = torch.empty((1, S, S, 1), dtype=torch.float32, device="cuda")
-        for _ in range(5):
-            g1.forward_device(x1, out=o1)
         torch.cuda.synchronize()
-        lat = []
-        for _ in range(30):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            g1.forward_device(x1, out=o1)
-            b.record()
-            b.synchronize()
-            lat.append(a.elapsed_time(b))
-        res["p50_ms_per_call_b1_eager"] = statistics.median(lat)
-        g1.use_graph(True)                                   # the launch plan as one HIP graph (same buffers every call)
-        for _ in range(3):
-            g1.forward_device(x1, out=o1)
-        torch.cuda.synchronize()
-        lat = []
-        for _ in range(30):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            g1.forward_device(x1, out=o1)
-            b.record()
-            b.synchronize()
-            lat.append(a.elapsed_time(b))
-        res["p50_ms_per_call_b1"] = statistics.median(lat)
+
+        def b1_latencies(n):
+            lat = []
+            for _ in range(n):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                g1.forward_device(x1, out=o1)
+                b.record()
+                b.synchronize()
+                lat.append(a.elapsed_time(b))
+            return lat
+
+        # on a stream of its own: the legacy default stream (torch's current stream otherwise) cannot be captured, and
+        # msr_forward then stays eager whatever msr_graph_enable says (round 2's "graph" figure was measured that way)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            for _ in range(5):
+                g1.forward_device(x1, out=o1)
+            torch.cuda.current_stream().synchronize()
+            res["p50_ms_per_call_b1_eager"] = statistics.median(b1_latencies(30))
+            g1.use_graph(True)                               # the launch plan as one HIP graph (same buffers every call)
+            for _ in range(4):                               # first sighting eager, second captures, then replays
+                g1.forward_device(x1, out=o1)
+            torch.cuda.current_stream().synchronize()
+            res["p50_ms_per_call_b1"] = statistics.median(b1_latencies(30))
         res["p50_ms_per_call_b1_note"] = (f"GauGAN({S},1,256): median of 30 single calls, each synchronised, B = 1, launch "
                                           "plan replayed as a HIP graph (msr_graph_enable); _eager = launched kernel by kernel")
         g1.close()

@@ -89,9 +89,12 @@ struct msr_handle {
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr;
     // HIP graphs of the launch plan, one per (input, noise, output) pointer triple (msr_graph_enable)
-    struct GraphEntry { const float* in; const float* eps; float* out; hipGraph_t graph; hipGraphExec_t exec; };
+    struct GraphEntry { const float* in; const float* eps; float* out; hipGraph_t graph; hipGraphExec_t exec; uint64_t last_use; };
+    struct Triple { const float* in; const float* eps; float* out; };
     int graph_on = 0;
-    std::vector<GraphEntry> graphs;
+    std::vector<GraphEntry> graphs;              // at most 8, least recently used evicted
+    std::vector<Triple> seen_once;               // triples run eagerly once: a triple is captured on its SECOND sighting
+    uint64_t graph_clock = 0;
     int gate_op = -1;                            // index of the first op of the matrix-bound part (msr_forward_gated)
     // profiling
     int prof_on = 0;                               // 0 off, 1 every launch, 2 runs of conv launches only
@@ -1230,10 +1233,15 @@ void drop_graphs(msr_handle* h) {
         if (g.graph) hipGraphDestroy(g.graph);
     }
     h->graphs.clear();
+    h->seen_once.clear();
 }
 
 int ensure_conv_partial(msr_handle* h, size_t floats) {
     if (floats <= h->conv_partial_floats) return MSR_OK;
+    if (!h->graphs.empty()) {      // instantiated graphs hold the old pointer: a replay would write split-K partials into freed memory
+        HIPCHK(h, hipDeviceSynchronize());
+        drop_graphs(h);
+    }
     if (h->conv_partial) HIPCHK(h, hipFree(h->conv_partial));
     h->conv_partial = nullptr;
     HIPCHK(h, hipMalloc(&h->conv_partial, floats * sizeof(float)));
@@ -1436,12 +1444,32 @@ int msr_forward(msr_handle* h, const float* in_dev, const float* eps_dev, float*
     // than a launch, and every cross-stream wait costs the stream ~16 us when issued eagerly).
     for (auto& g : h->graphs)
         if (g.in == in_dev && g.eps == eps_dev && g.out == out_dev) {
+            g.last_use = ++h->graph_clock;
             HIPCHK(h, hipGraphLaunch(g.exec, s));
             return MSR_OK;
         }
-    if (h->graphs.size() >= 8 || s == nullptr)       // callers that never repeat a triple stay eager; the legacy default
-        return launch_all(h, in_dev, eps_dev, out_dev, s);   // stream cannot be captured
-    msr_handle::GraphEntry e{in_dev, eps_dev, out_dev, nullptr, nullptr};
+    if (s == nullptr) return launch_all(h, in_dev, eps_dev, out_dev, s);     // the legacy default stream cannot be captured
+    // A triple is captured on its second sighting: a caller that draws a fresh noise tensor (a fresh pointer) per call
+    // never pays capture + instantiate, and never fills the cache with one-shot graphs.
+    {
+        bool seen = false;
+        for (auto& t : h->seen_once) seen |= t.in == in_dev && t.eps == eps_dev && t.out == out_dev;
+        if (!seen) {
+            if (h->seen_once.size() >= 16) h->seen_once.erase(h->seen_once.begin());
+            h->seen_once.push_back({in_dev, eps_dev, out_dev});
+            return launch_all(h, in_dev, eps_dev, out_dev, s);
+        }
+    }
+    if (h->graphs.size() >= 8) {                      // evict the least recently used graph (nothing of it may still run)
+        size_t lru = 0;
+        for (size_t k = 1; k < h->graphs.size(); ++k)
+            if (h->graphs[k].last_use < h->graphs[lru].last_use) lru = k;
+        HIPCHK(h, hipDeviceSynchronize());
+        if (h->graphs[lru].exec) hipGraphExecDestroy(h->graphs[lru].exec);
+        if (h->graphs[lru].graph) hipGraphDestroy(h->graphs[lru].graph);
+        h->graphs.erase(h->graphs.begin() + lru);
+    }
+    msr_handle::GraphEntry e{in_dev, eps_dev, out_dev, nullptr, nullptr, ++h->graph_clock};
     HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
     rc = launch_all(h, in_dev, eps_dev, out_dev, s);
     hipError_t ce = hipStreamEndCapture(s, &e.graph);

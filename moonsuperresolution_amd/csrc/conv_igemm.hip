@@ -64,7 +64,19 @@ struct TileGeom {
     int th_l, tw_l, tb;            // log2 tile height/width, samples per tile
     int tiles_x, tiles_y, tiles_b, tiles_n;
     int tiles_mn;                  // tiles_x * tiles_y * tiles_b * tiles_n (the grid is ksplit times that)
+    // Tile walk of the persistent kernels (conv_walk, below): consecutive tile numbers cover walk_nb channel blocks of
+    // walk_pb pixel tiles before they move to the next channel blocks of the same pixel tiles.  (1, tiles_n) = channel
+    // block fastest (the round-2 walk).
+    int walk_pb, walk_nb;
 };
+
+void conv_walk_pick(int tiles_m, int tiles_n, int* walk_pb, int* walk_nb) {
+    static const bool off = std::getenv("MSR_TILE_WALK") && std::atoi(std::getenv("MSR_TILE_WALK")) == 0;
+    *walk_pb = 1;
+    *walk_nb = tiles_n;
+    if (!off && tiles_n > 4 && tiles_n % 4 == 0 && tiles_m % 8 == 0) { *walk_pb = 8; *walk_nb = 4; }
+}
+static void conv_walk(TileGeom& g) { conv_walk_pick(g.tiles_x * g.tiles_y * g.tiles_b, g.tiles_n, &g.walk_pb, &g.walk_nb); }
 
 // ------------------------------------------------------------------------------------------------------
 // Epilogue shared by the fp32 and the split-bf16 kernels.
@@ -1279,8 +1291,8 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
     {                                                                                            \
         KS_ = (T_) / g.tiles_mn;                                                                 \
         const int t_ = (T_) - KS_ * g.tiles_mn;                                                  \
-        const int tn_ = t_ % g.tiles_n;                                                          \
-        int tmi_ = t_ / g.tiles_n;                                                               \
+        int tn_, tmi_;                                                                           \
+        MSR_WALK(g, t_, tn_, tmi_)                                                               \
         TX_ = (tmi_ % g.tiles_x) << 4;                                                           \
         tmi_ /= g.tiles_x;                                                                       \
         TY_ = (tmi_ % g.tiles_y) << 4;                                                           \
@@ -1836,6 +1848,8 @@ static bool make_geom(const ConvParams& p, int BM, int BN, int BKC, TileGeom& g)
     g.tiles_b = (p.B + tb - 1) / tb;
     g.tiles_n = p.N / BN;
     g.tiles_mn = g.tiles_x * g.tiles_y * g.tiles_b * g.tiles_n;
+    g.walk_pb = 1;
+    g.walk_nb = g.tiles_n;
     return true;
 }
 
@@ -2030,6 +2044,7 @@ static hipError_t launch_pp(const ConvParams& p, int epi, hipStream_t s) {
     TileGeom g;
     if (!make_geom(p, 256, 128, 32, g)) return hipErrorInvalidValue;
     const bool one = p.prec == PREC_FP8 && p.Cin == 32;            // one 128-byte chunk: two tiles per unrolled body
+    if (!one) conv_walk(g);
     if (g.tb != 1 || g.th_l != 4 || g.tw_l != 4 || p.stride != 1 || p.KH != 3 || p.KW != 3 || (!one && p.Cin % 64))
         return hipErrorInvalidValue;
     const int ksn = p.ksplit > 1 ? p.ksplit : 1;

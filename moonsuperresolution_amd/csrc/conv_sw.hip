@@ -40,6 +40,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct SwGeom {
     int tiles_x, tiles_y, tiles_n, tiles_mn;   // 16 x 16 pixel tiles per row / column, 128-column blocks, all tiles
+    int walk_pb, walk_nb;                      // tile walk (kernels.h conv_walk_pick / MSR_WALK)
 };
 
 static constexpr int SW_HW = 18, SW_HP = 18 * 18, SW_BKP = 40, SW_HPB = SW_HP * SW_BKP;   // floats per halo buffer
@@ -225,8 +226,8 @@ conv_igemm_f16c_sw(const ConvParams p, const SwGeom g) {
 #define SW_DECODE(T_, N0_, TX_, TY_, B_, HT_, WT_)                                               \
     {                                                                                            \
         const int t_ = (T_);                                                                     \
-        const int tn_ = t_ % g.tiles_n;                                                          \
-        int tmi_ = t_ / g.tiles_n;                                                               \
+        int tn_, tmi_;                                                                           \
+        MSR_WALK(g, t_, tn_, tmi_)                                                               \
         TX_ = (tmi_ % g.tiles_x) << 4;                                                           \
         tmi_ /= g.tiles_x;                                                                       \
         TY_ = (tmi_ % g.tiles_y) << 4;                                                           \
@@ -562,6 +563,7 @@ hipError_t launch_conv_f16c_sw(const ConvParams& p, int epi, hipStream_t s) {
     g.tiles_y = p.Hout / 16;
     g.tiles_n = p.N / 128;
     g.tiles_mn = g.tiles_x * g.tiles_y * p.B * g.tiles_n;
+    conv_walk_pick(g.tiles_x * g.tiles_y * p.B, g.tiles_n, &g.walk_pb, &g.walk_nb);
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;

@@ -253,6 +253,26 @@ __device__ inline void msr_store_f16c4_dev(float* pixel, int c, float v0, float 
 
 enum ConvTile : int { TILE_128x128 = 0, TILE_64x64 = 1, TILE_128x128_K16 = 2, TILE_128x128_HALO = 3, TILE_128x128_HALO16 = 4, TILE_256x128_PP = 5 };
 
+// Which tiles an XCD's 32 CUs hold at the same time decides what its 4 MB L2 must serve: a pixel tile's input halo is
+// shared by the CUs that work on its channel blocks, a channel block's weights by the CUs that work on different pixel
+// tiles.  Channel block fastest (all of a pixel tile's N / 128 blocks side by side) streams the WHOLE weight tensor
+// through the L2 once per round of 32 tiles: measured (profiles/r03_spade512_f16c_traffic_by_layer_before.txt) 604 MB of
+// weight re-reads per launch on the N = 2048 / 1024 gamma|beta convs, 3-4x their algorithmic bytes.  With 8 pixel tiles x
+// 4 channel blocks per round the weights are read once per 8 pixel tiles and a halo at most N / 512 times: per-XCD bytes
+// ~ w / 8 + h * 8 / 32 per tile instead of w / 2 + h / 16 (N = 2048; w = 590 KB of weights per channel block at Cin = 128,
+// h = 166 KB of halo), the minimum over the splits of 32.  MSR_TILE_WALK=0 restores channel block fastest (A/B runs).
+void conv_walk_pick(int tiles_m, int tiles_n, int* walk_pb, int* walk_nb);
+// tile number -> (channel block, pixel tile) under the walk
+#define MSR_WALK(g, t_, tn_, tmi_)                                                               \
+    {                                                                                            \
+        const int grp_ = (g).walk_pb * (g).tiles_n, sub_ = (g).walk_pb * (g).walk_nb;            \
+        const int blk_ = (t_) / grp_, rem_ = (t_) - blk_ * grp_;                                 \
+        const int ng_ = rem_ / sub_, j_ = rem_ - ng_ * sub_;                                     \
+        const int jp_ = j_ / (g).walk_nb;                                                        \
+        tn_ = ng_ * (g).walk_nb + (j_ - jp_ * (g).walk_nb);                                      \
+        tmi_ = blk_ * (g).walk_pb + jp_;                                                         \
+    }
+
 hipError_t conv_igemm_init();   // sets dynamic-LDS attributes once
 // conv_sw.hip: PREC_F16C whole-tile launches as one software-pipelined wave per SIMD.  launch_conv_igemm sends it the
 // long-K main convs (bias / residual epilogues, Cin % 128 == 0); MSR_F16C_SW = 0 keeps everything on the ping-pong kernel,

@@ -271,7 +271,7 @@ hipError_t launch_stitch_tile(const float* pred, const int* key, const float* dm
 // rank's gives the accumulators of the union:
 //     w = wa + wb,  d = mb - ma,  mean = ma + d * wb / w,  S = Sa + Sb + d^2 * wa * wb / w
 // evaluated in float64, then finalised like rebuildTile (process_full_tiles.py:409-413): good = w > 0,
-// std = sqrt(S / w), no_value where not good.  b == nullptr finalises a alone.
+// std = sqrt(max(S, 0) / w), no_value where not good.  b == nullptr finalises a alone.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) halo_merge_kernel(const float* __restrict__ wa, const float* __restrict__ ma,
                                                          const float* __restrict__ sa, const float* __restrict__ wb,
@@ -295,7 +295,10 @@ __global__ void __launch_bounds__(256) halo_merge_kernel(const float* __restrict
         }
         const bool good = w > 0.0;
         mean_o[i] = good ? (float)m : no_value;
-        std_o[i] = good ? sqrtf((float)S / (float)w) : no_value;
+        // float32 rounding of the West update / the Chan combine can leave S a hair below zero: clamp, so that the
+        // standard deviation is finite wherever good == 1 (NaN in S still propagates: fmaxf is not used)
+        const float Sf = (float)S < 0.f ? 0.f : (float)S;
+        std_o[i] = good ? sqrtf(Sf / (float)w) : no_value;
         good_o[i] = good ? 1 : 0;
     }
 }

@@ -35,6 +35,11 @@ class HaloShardedSuperResolution(DEMSuperResolution):
     def patchGrid(self) -> Tuple[list, list]:
         """Unique patch origins the reference's tiles touch (padded-canvas coordinates): (ys, xs), sorted."""
         S, s, T = self.image_size, self.stride, self.tile_size
+        if S % s or T % s:
+            # msr_stitch_partial bins patches by (origin - block origin) / stride: origins that are not multiples of the
+            # stride relative to every T x T block would be dropped silently (and the union grid would be irregular)
+            raise ValueError(f"halo mode needs a stride that divides image_size and tile_size (got stride {s}, "
+                             f"image_size {S}, tile_size {T}); use the tile mode (processMap) for other strides")
         span = T + S - s
         ys = sorted({y for _, py in self.generateTileList() for y in range(py, py + span, s)})
         xs = sorted({x for px, _ in self.generateTileList() for x in range(px, px + span, s)})

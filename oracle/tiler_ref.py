@@ -270,7 +270,9 @@ def halo_finalize(acc, no_value: float):
     w_sum, mean, s_acc = acc
     good = w_sum > 0
     with np.errstate(invalid="ignore", divide="ignore"):
-        std = np.sqrt(s_acc / w_sum)
+        # S clamped at zero (float32 rounding can leave it slightly negative): std is finite wherever good == 1;
+        # np.where keeps a NaN in S a NaN (np.maximum would too, but the kernel's comparison form is mirrored)
+        std = np.sqrt(np.where(s_acc < 0, np.float32(0), s_acc).astype(np.float32) / w_sum)
     mean = np.where(good, mean, np.float32(no_value)).astype(np.float32)
     std = np.where(good, std, np.float32(no_value)).astype(np.float32)
     return mean, std, good.astype(np.uint8)

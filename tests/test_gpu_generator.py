@@ -92,12 +92,22 @@ def test_graph_replay_equals_eager(Generator):
     st = torch.cuda.Stream()
     outs = [torch.empty((2, 64, 64, 1), device="cuda") for _ in range(3)]
     with torch.cuda.stream(st):
-        for o in outs + outs:                        # first pass captures, second replays
+        for o in outs + outs + outs:                 # first pass eager (first sighting), second captures, third replays
             gen.forward_device(x, out=o)
         st.synchronize()
         assert all(torch.equal(o, ref) for o in outs)
+        # more repeating triples than the cache holds (8): the least recently used graph is evicted, results stay right
+        many = [torch.empty((2, 64, 64, 1), device="cuda") for _ in range(10)]
+        for o in many + many + many:
+            gen.forward_device(x, out=o)
+        st.synchronize()
+        assert all(torch.equal(o, ref) for o in many)
+        # one-shot triples (a fresh output per call) never evict the graphs of the repeating ones
+        for _ in range(20):
+            assert torch.equal(gen.forward_device(x, out=torch.empty((2, 64, 64, 1), device="cuda")), ref)
         xin = x.clone()
         gen.forward_device(xin, out=outs[0])
+        gen.forward_device(xin, out=outs[0])         # second sighting: captured
         xin.copy_(x_other)                           # same pointer, new content: the graph reads the buffer, not a copy
         gen.forward_device(xin, out=outs[0])
         st.synchronize()

@@ -4,7 +4,7 @@
 What is compared with what, and to which tolerance:
   * identity model, one rank: the mean equals the TILE mode's mean bit for bit (every pixel sees the same patches in
     the same order; only the batch cut differs, which the identity model does not feel); std equals the oracle's
-    textbook-West std bit for bit (NaN where float32 rounding drives S below zero, as NumPy does);
+    textbook-West std bit for bit (S clamped at zero before the square root: finite wherever good == 1);
   * identity model, 2 and 3 simulated ranks (accumulate per rank, hand the boundary zones over in-process, finish):
     bit-exact against the oracle run with the same number of ranks; <= 1e-6 relative against one rank (pairwise
     instead of sequential combination in the zones);
@@ -58,6 +58,7 @@ def test_identity_model_halo_mode(hip_lib, S, stride, B, T, shape, hole):
     for a, b in zip(one, ref1):
         assert np.array_equal(a, b, equal_nan=True)
     ok = one[2] == 1
+    assert np.isfinite(one[1][ok]).all() and (one[1][ok] >= 0).all()     # S is clamped at zero: no NaN where good == 1
     for world in (2, 3):
         got = run_halo(d, img, dem, world)
         ref = tiler_ref.process_map_halo(img, dem, f32_identity, S, stride, B, T, NOVAL, world=world)
@@ -67,6 +68,19 @@ def test_identity_model_halo_mode(hip_lib, S, stride, B, T, shape, hole):
         scale = float(np.abs(one[0][ok]).max())
         assert float(np.abs(got[0][ok] - one[0][ok]).max()) <= 1e-6 * scale
     d.close()
+
+
+def test_halo_mode_rejects_a_stride_that_does_not_divide(hip_lib):
+    """msr_stitch_partial bins patches by origin / stride relative to each T x T block: with S % s or T % s the
+    patches would be dropped without an error, so the mode refuses such a configuration (the tile mode accepts it)."""
+    from moonsuperresolution_amd import DSRConfig, HaloShardedSuperResolution
+    img, dem = synthetic_raster(150, 140, 3)
+    for S, stride, T in ((64, 24, 128), (64, 16, 120)):
+        d = HaloShardedSuperResolution(DSRConfig(image_size=S, stride=stride, batch_size=4, tile_size=T), model=f32_identity)
+        d.setImages(img, dem)
+        with pytest.raises(ValueError, match="stride"):
+            d.haloAccumulate(0, 1)
+        d.close()
 
 
 def test_generator_halo_mode_vs_oracle_and_tile_mode(hip_lib):
