@@ -261,6 +261,19 @@ int msr_op_conv3x3_f16c(msr_handle* h, const float* in_dev, const float* wt_dev,
                         const float* bias_dev, float* out_dev, int32_t B, int32_t rout, int32_t Cin, int32_t N,
                         int32_t epilogue, const float* aux_dev, int32_t aux_shift, const float* mean_dev,
                         const float* std_dev, int32_t out_padded, int32_t out_mode, void* stream);
+/* Kernel-level entry of conv_gb_resident (csrc/conv_gbr.hip): ONE SPADE layer's modulation path in one launch —
+ *   nearest resize of src to r x r + Conv2D(128, 3, relu) (spade.py:17-18), conv_gamma | conv_beta (spade.py:19-20) as one
+ *   GEMM with N = 2C columns interleaved (32 gamma | 32 beta), gamma * (x - mean) / std + beta (spade.py:21-24), leaky_relu(0.2)
+ *   (blocks.py:30-34), written as the f16c chunk image of the consumer conv.
+ *   src_dev  [B, S, S, 2] fp32 (S = r * 2^k); we_dev HWIO [3,3,2,128]; be_dev [128]
+ *   wt_dev   f16c6 image (ops.f16c6_weight_image) of [9][N][128] with the input channels of every 32-chunk in the kernel's
+ *            position order: position e holds channel 8 * (e >> 3) + 4 * (e & 1) + ((e >> 1) & 3)
+ *   bias_dev [N] in column order; aux_dev = x [B, r >> aux_shift, r >> aux_shift, N / 2]; mean_dev / std_dev [N / 2]
+ *   out_dev  zero-bordered [B, r + 2, r + 2, N / 2] float slots, the interior is written
+ * Needs r >= 32 (a power of two) and N % 128 == 0; MSR_ERR_INVALID otherwise. */
+int msr_op_spade_gbr(msr_handle* h, const float* src_dev, int32_t S, const float* we_dev, const float* be_dev,
+                     const float* wt_dev, const float* bias_dev, float* out_dev, int32_t B, int32_t r, int32_t N,
+                     const float* aux_dev, int32_t aux_shift, const float* mean_dev, const float* std_dev, void* stream);
 /* HOST helper: the fp32 -> fp8 e4m3 (OCP "fn", round to nearest even, saturating at 448) conversion msr_load_weight
  * applies to the weights of the fp8 mode, exposed so that it can be checked against an independent implementation. */
 int64_t msr_quantize_e4m3(const float* host, int64_t n, uint8_t* out);

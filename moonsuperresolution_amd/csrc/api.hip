@@ -26,7 +26,7 @@ struct WeightSpec {
     bool loaded = false;
 };
 
-enum OpType { OP_CONV, OP_SMALLCIN, OP_MOMENTS, OP_MOMENTS_SLABS, OP_NORMACT, OP_DENSE, OP_LATENT, OP_HEAD, OP_DIRECT };
+enum OpType { OP_CONV, OP_SMALLCIN, OP_MOMENTS, OP_MOMENTS_SLABS, OP_NORMACT, OP_DENSE, OP_LATENT, OP_HEAD, OP_DIRECT, OP_GBR };
 enum Family { FAM_CONV = 0, FAM_SMALLCIN, FAM_MOMENTS, FAM_NORMACT, FAM_DENSE, FAM_LATENT, FAM_HEAD, FAM_DIRECT,
               FAM_COUNT };
 const char* kFamilyName[FAM_COUNT] = {"conv_igemm", "conv_smallcin", "moments", "norm_act", "dense",
@@ -44,6 +44,7 @@ struct Op {
     ConvParams conv{}; int epi = 0, tile = 0;
     int stat_slabs = 0;               // > 0: the conv's epilogue also writes partial output moments (fused)
     SmallCinParams sc{};
+    GbrParams gbr{};                  // OP_GBR: mask embedding + gamma|beta conv + SPADE epilogue in one launch (conv_gbr.hip)
     struct { const float* x; int G, P, C; float eps; float* mean; float* stdv; } mom{};
     NormActParams na{};
     struct { const float* x; const float* W; const float* bias; float* y; int B, K, N; } dense{};
@@ -329,6 +330,19 @@ bool main_uses_f16c(msr_handle* h, int rout, int cin, int cout) {
     return h->f16c && cin % 64 == 0 && conv_on_pp_f16c(h->B, rout, cout, cin) && conv_on_pp_f16c(h->B, rout, 2 * cin, 128);
 }
 
+// conv_gb_resident (conv_gbr.hip) takes a SPADE layer whose gamma|beta conv AND consumer conv run f16c, when the layer has
+// enough 16 x 16 pixel tiles x channel-block ranges to fill the chip (conv_gbr_ranges; MSR_GBR=0 switches it off).  Its
+// weights are the f16c6 image with the input channels of every 32-chunk in the kernel's position order (GBR_PERM below).
+bool main_uses_f16c(msr_handle* h, int rout, int cin, int cout);
+bool main_uses_f16c6(msr_handle* h, int rout, int cin, int cout);
+bool gb_uses_gbr(msr_handle* h, int rout, int C, int cout) {
+    return h->f16c && gb_uses_f16c(h, rout, C) && main_uses_f16c(h, rout, C, cout) && !main_uses_f16c6(h, rout, C, cout) &&
+           conv_gbr_ranges(h->B, rout, 2 * C) > 0;
+}
+// position e of a 32-channel chunk holds channel GBR_PERM(e): the order in which phase 1 of conv_gb_resident leaves a pixel's
+// channels in a lane (32 x 32 MFMA rows 8q + 4h + r, halves interleaved by v_cvt_scalef32_2xpk16_fp6_f32)
+inline int gbr_perm(int e) { return 8 * (e >> 3) + 4 * (e & 1) + ((e >> 1) & 3); }
+
 // PREC_F16C6 (fp6 cross terms, kernels.h), OPT-IN with MSR_F16C_FP6=1: the main convs that run the stream kernel (conv_sw.hip:
 // whole tiles, Cin % 128 == 0) behind a gamma|beta conv that is a whole-tile ping-pong launch (its LDS-assembled epilogue
 // writes the fp6 image).  Measured: the consumer gains 6.5 % on those convs, the producer's block-scale and 6-bit
@@ -551,7 +565,7 @@ int msr_create(const msr_config* cfg, msr_handle** out) {
         return fail(nullptr, MSR_ERR_STATE, "this libmoonsr_hip.so is a diagnostic build (-DMSR_DIAG_BUILD: in-kernel stamps "
                     "or what-if switches that change results); set MSR_ALLOW_DIAG_BUILD=1 to use it for measurements");
 #endif
-    if (conv_igemm_init() != hipSuccess)
+    if (conv_igemm_init() != hipSuccess || conv_gbr_init() != hipSuccess)
         return fail(nullptr, MSR_ERR_DEVICE, "could not set the dynamic-LDS attribute of the conv kernels");
     auto h = std::make_unique<msr_handle>();
     h->cfg = *cfg;
@@ -728,7 +742,16 @@ int msr_load_weight(msr_handle* h, const char* name_c, const float* host, const 
             hwio_to_tap_oc_ic(host, img.data(), 9, cin, C, 2 * C, rowmap.data());
             int rout = 0, stride = 1;
             weight_conv_shape(h, name, &rout, &stride);
+            int blk = 0, sj = 0;
+            std::sscanf(name.c_str(), "gen.rb%d.spade_%d.", &blk, &sj);
+            const int cout_main = blk >= 1 && blk <= 6 ? kGenFilters[blk - 1] : 0;     // every conv of block i has kGenFilters[i-1] outputs
             if (gb_uses_fp8(h, rout, C)) rc = upload_conv_weight_fp8(h, base + ".gb.kernel", img.data(), 9, 2 * C, cin);
+            else if (cin == 128 && cout_main && gb_uses_gbr(h, rout, C, cout_main)) {
+                std::vector<float> perm(img.size());
+                for (size_t row = 0; row < (size_t)9 * 2 * C; ++row)
+                    for (int k = 0; k < cin; ++k) perm[row * cin + k] = img[row * cin + (k & ~31) + gbr_perm(k & 31)];
+                rc = upload_conv_weight_f16c6(h, base + ".gb.kernel", perm.data(), 9, 2 * C, cin);
+            }
             else if (gb_uses_f16c(h, rout, C)) rc = upload_conv_weight_f16c(h, base + ".gb.kernel", img.data(), 9, 2 * C, cin);
             else
                 rc = upload_conv_weight(h, base + ".gb.kernel", img.data(), img.size(), 9, 2 * C, cin,
@@ -979,8 +1002,28 @@ int plan_spade(msr_handle* h) {
             const bool gb8 = gb_uses_fp8(h, r, C), cv8 = main_uses_fp8(h, r, C, f);
             const bool gbc = gb_uses_f16c(h, r, C), cvc = main_uses_f16c(h, r, C, f), cv6 = main_uses_f16c6(h, r, C, f);
             const int hslots = gb8 ? fp8_pad(128) / 4 : 128, aslots = cv8 ? fp8_pad(C) / 4 : C;
-            snprintf(k, sizeof k, "ws.gen.rb%d.h%d", i, j); int rc2 = alloc_padded(h, k, r, hslots, &hb); if (rc2) return rc2;
+            const bool gbr = gb_uses_gbr(h, r, C, f);
+            int rc2;
             snprintf(k, sizeof k, "ws.gen.rb%d.a%d", i, j); rc2 = alloc_padded(h, k, r, aslots, &ab); if (rc2) return rc2;
+            if (gbr) {
+                // conv_gb_resident: the embedding never exists in HBM (no mask-embedding launch, no h buffer); one launch
+                // does resize + embedding + gamma|beta conv + SPADE epilogue and writes the consumer's f16c image
+                Op g; g.type = OP_GBR; g.src_is_input = true;
+                GbrParams& q = g.gbr;
+                snprintf(k, sizeof k, "gen.rb%d.spade_%d.conv.kernel", i, j); q.we = need(k);
+                snprintf(k, sizeof k, "gen.rb%d.spade_%d.conv.bias", i, j); q.be = need(k);
+                q.S = S; q.f = S / r; q.o = (S / r) / 2;
+                snprintf(k, sizeof k, "gen.rb%d.spade_%d.gb.kernel", i, j); q.wt = need(k);
+                snprintf(k, sizeof k, "gen.rb%d.spade_%d.gb.bias", i, j); q.bias = need(k);
+                q.aux = x; q.aux_px = C; q.aux_py = rx * C; q.aux_pb = rx * rx * C; q.aux_shift = xshift;
+                q.mean = mean; q.stdv = stdv;
+                q.out = ab.base; q.out_px = ab.C; q.out_py = ab.py(); q.out_pb = ab.pb(); q.out_off = ab.interior();
+                q.out_split = 4; q.slope = 0.2f;
+                q.B = B; q.r = r; q.N = 2 * C;
+                g.flops = 2.0 * B * r * r * 128.0 * (2 * C) * 9 + 2.0 * B * r * r * 18.0 * 128;
+                h->ops.push_back(g);
+            } else {
+            snprintf(k, sizeof k, "ws.gen.rb%d.h%d", i, j); rc2 = alloc_padded(h, k, r, hslots, &hb); if (rc2) return rc2;
             Op em; em.type = OP_SMALLCIN; em.src_is_input = true;
             SmallCinParams& p = em.sc;
             snprintf(k, sizeof k, "gen.rb%d.spade_%d.conv.kernel", i, j); p.w = need(k);
@@ -1026,6 +1069,7 @@ int plan_spade(msr_handle* h) {
             gb.wait = em.done;
             gb.aux_group = em.aux_group;
             h->ops.push_back(gb);
+            }
             snprintf(k, sizeof k, "gen.rb%d.conv_%d.kernel", i, conv_idx); const float* cw = need(k);
             snprintf(k, sizeof k, "gen.rb%d.conv_%d.bias", i, conv_idx); const float* cb = need(k);
             Op cv = conv_op(ab, cw, cb, B, r, f, 1, epi, h->prec);
@@ -1274,7 +1318,8 @@ int ensure_plan(msr_handle* h) {
     h->fwd_flops = 0;
     h->gate_op = -1;
     for (size_t k = 0; k < h->ops.size(); ++k)
-        if (h->ops[k].type == OP_CONV && h->ops[k].tile == TILE_256x128_PP && h->ops[k].conv.ksplit == 1) {
+        if (h->ops[k].type == OP_GBR ||
+            (h->ops[k].type == OP_CONV && h->ops[k].tile == TILE_256x128_PP && h->ops[k].conv.ksplit == 1)) {
             h->gate_op = (int)k;     // first layer that fills the chip with persistent ping-pong tiles
             break;
         }
@@ -1351,11 +1396,11 @@ int launch_all(msr_handle* h, const float* in_dev, const float* eps_dev, float* 
             if (h->prof_on == 2) close_run();
             HIPCHK(h, hipStreamWaitEvent(s, gate, 0));
         }
-        if (h->prof_on == 2 && (op.type != OP_CONV || (use_aux && op.wait))) close_run();
+        if (h->prof_on == 2 && ((op.type != OP_CONV && op.type != OP_GBR) || (use_aux && op.wait))) close_run();
         if (use_aux && op.wait) HIPCHK(h, hipStreamWaitEvent(s, op.wait, 0));
         hipEvent_t ea = nullptr, eb = nullptr;
         if (h->prof_on == 1) { ea = get_event(h); eb = get_event(h); hipEventRecord(ea, s); }
-        if (h->prof_on == 2 && op.type == OP_CONV) {
+        if (h->prof_on == 2 && (op.type == OP_CONV || op.type == OP_GBR)) {
             if (run.launches == 0) { run.a = get_event(h); hipEventRecord(run.a, s); }
             run.launches += 1;
             run.flops += op.flops;
@@ -1404,6 +1449,13 @@ int launch_all(msr_handle* h, const float* in_dev, const float* eps_dev, float* 
                 e = launch_head(op.head.x, op.head.weff, op.head.bias, out_dev, op.head.B, op.head.r, op.head.C,
                                 op.head.slope, op.head.tanh_out, op.head.x_py, op.head.x_pb, s);
                 break;
+            case OP_GBR: {
+                fam = FAM_CONV;
+                GbrParams q = op.gbr;
+                q.src = in_dev;
+                e = launch_conv_gbr(q, conv_gbr_ranges(q.B, q.r, q.N), s);
+                break;
+            }
             case OP_DIRECT: {
                 fam = FAM_DIRECT;
                 DirectConvParams p = op.dc;
@@ -1606,6 +1658,30 @@ int msr_op_conv3x3_f16c(msr_handle* h, const float* in_dev, const float* wt_dev,
     op.conv.mean = mean_dev; op.conv.stdv = std_dev;
     hipError_t e = launch_conv_igemm(op.conv, epilogue, op.tile, (hipStream_t)stream);
     if (e != hipSuccess) return fail(h, MSR_ERR_INVALID, "f16c conv launch rejected: %s", hipGetErrorString(e));
+    return MSR_OK;
+}
+
+int msr_op_spade_gbr(msr_handle* h, const float* src_dev, int32_t S, const float* we_dev, const float* be_dev,
+                     const float* wt_dev, const float* bias_dev, float* out_dev, int32_t B, int32_t r, int32_t N,
+                     const float* aux_dev, int32_t aux_shift, const float* mean_dev, const float* std_dev, void* stream) {
+    if (!h) return MSR_ERR_INVALID;
+    if (!src_dev || !we_dev || !be_dev || !wt_dev || !bias_dev || !out_dev || !aux_dev || !mean_dev || !std_dev || B < 1 ||
+        r < 32 || S < r || S % r || N % 128 || aux_shift < 0 || aux_shift > 1)
+        return fail(h, MSR_ERR_INVALID, "msr_op_spade_gbr: bad argument (r >= 32, S a multiple of r, N %% 128 == 0)");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int C = N / 2, rx = r >> aux_shift;
+    GbrParams q{};
+    q.src = src_dev; q.we = we_dev; q.be = be_dev; q.S = S; q.f = S / r; q.o = (S / r) / 2;
+    q.wt = wt_dev; q.bias = bias_dev;
+    q.aux = aux_dev; q.aux_px = C; q.aux_py = rx * C; q.aux_pb = rx * rx * C; q.aux_shift = aux_shift;
+    q.mean = mean_dev; q.stdv = std_dev;
+    Padded o; o.base = out_dev; o.r = r; o.C = C;
+    q.out = o.base; q.out_px = C; q.out_py = o.py(); q.out_pb = o.pb(); q.out_off = o.interior();
+    q.out_split = 4; q.slope = 0.2f; q.B = B; q.r = r; q.N = N;
+    int ranges = conv_gbr_ranges(B, r, N);       // the planner's split; a layer it would not take runs one item per pixel tile
+    if (ranges < 1) ranges = 1;
+    hipError_t e = launch_conv_gbr(q, ranges, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(h, MSR_ERR_INVALID, "conv_gb_resident launch rejected: %s", hipGetErrorString(e));
     return MSR_OK;
 }
 

@@ -1,0 +1,505 @@
+// conv_gb_resident — one SPADE layer's whole modulation path in ONE kernel (round 3):
+//     mask = nearest_resize(source)            spade.py:17   (tf.image.resize, method="nearest")
+//     e    = relu(conv3x3(mask, 2 -> 128))     spade.py:18   (self.conv, activation="relu")
+//     g|b  = conv3x3(e, 128 -> 2C)             spade.py:19-20 (conv_gamma, conv_beta as ONE GEMM, kernels.h EPI_SPADE)
+//     out  = leaky_relu(g * (x - mean) / std + b)   spade.py:21-24 + blocks.py:30-34
+// for the launches that fill the chip (r >= 32 at the BASELINE sizes: 98 % of the gamma|beta FLOPs).
+//
+// Why: the gamma|beta convs are half of a call's FLOPs and ran the ping-pong kernel at 53-56 % matrix-pipe busy with NO memory
+// resource near its limit (profiles/r03_conv_colimiters_f16c_before.txt: TA 36 %, LDS 38 %): the loss was the schedule — two
+// barriers per K-step, an even / odd step imbalance, tile ends every 36 K-steps.  Their K is only 9 x 128, so the input of a
+// 16 x 16 pixel tile is small enough to stay in LDS for ALL output channels, and it is a function of the call's 2-channel
+// input alone, so it does not have to exist in HBM at all:
+//   * phase 1 (per work item): the 18 x 18 pixel halo of the 128-channel embedding is COMPUTED here from a 20 x 20 patch of the
+//     resized mask (fp32 FMA chain: bias, then (ky, kx, c) order) and written to LDS as the f16c6 operand (kernels.h PREC_F16C6:
+//     fp16 main term + fp6 e2m3 cross pieces, one power-of-two scale per pixel and 32-channel chunk).  The fp6 pieces are what
+//     makes it fit: 324 px x 4 chunks x (64 + 24 + 24) B = 145 KB; with fp8 pieces it is 166 KB.  The 15 mask-embedding kernels
+//     of a call (1.33 GB written, then re-read ~3x, 1.47 ms of kernel time on the auxiliary stream) are gone for these layers.
+//   * phase 2: the workgroup sweeps its channel blocks (128 GEMM columns each) over the resident halo with the stream kernel's
+//     body (conv_sw.hip): four waves, one per SIMD, wave q owns all 256 pixels x 32 columns, its weights go global -> registers
+//     a tap pair ahead, pixel fragments stream from LDS through a register ring.  No LDS write, no barrier and no halo load
+//     inside the sweep: the only vector-memory traffic is the weight stream (16 KB per tap pair and wave).
+//     A tap pair = 32 + 32 f16 MFMAs (x_hi * w_hi of two taps) + 32 block-scaled K = 128 fp6 MFMAs (16 cycles each: both cross
+//     terms of both taps) = 1.5 MFMA-equivalents per product instead of f16c's 2.
+//   * epilogue per channel block: the SPADE modulation, written as the consumer's f16c chunk image; a wave holds 16 of a
+//     chunk's 32 channels, so the 64 bytes a pixel gets from it (32 B fp16 | 16 B h8 | 16 B l8) are assembled in a private LDS
+//     line and leave as ONE 16-byte store per lane and tile row.
+// LDS (plane layout, every plane has a pixel pitch of 336 = 324 + 12):
+//   F[chunk][piece 0..3][336] x 16 B   fp16 of channels 8 * piece .. + 7          86,016 B   (ds_read_b128: 16 consecutive
+//                                       pixels of two planes whose distance is 0 mod 16 slots -> conflict-free for any base)
+//   X[chunk][kind h6 | l6][j 0..2][336] x 8 B   the j-th 8 bytes of a 24-byte fp6 piece   64,512 B   (ds_read_b64: pitch
+//                                       16 mod 32 -> the two kinds of a 32-lane group use disjoint bank halves)
+//   SC[chunk][kind][336] x 1 B          e8m0 of the piece (h6: E, l6: E - 11)      2,688 B
+//   stage[wave] 2,560 B                 epilogue line assembly (phase 1: the 20 x 20 x 2 mask patch)   -> 163,456 B
+#include "kernels.h"
+#include <cstdlib>
+
+namespace msr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x6 __attribute__((ext_vector_type(6)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+static constexpr int GB_PH = 336;
+static constexpr int GB_F_BYTES = 16 * GB_PH * 16;
+static constexpr int GB_X_BYTES = 24 * GB_PH * 8;
+static constexpr int GB_SC_BYTES = 8 * GB_PH;
+static constexpr int GB_STAGE_OFF = GB_F_BYTES + GB_X_BYTES + GB_SC_BYTES;
+static constexpr int GB_STAGE_WAVE = 2560;
+static constexpr int GB_LINE = 80;                                   // bytes per staged pixel line (64 used)
+#ifdef MSR_GB_STAMPS
+static constexpr size_t GB_LDS = 163840;                             // the stamp words take the last 384 bytes
+#else
+static constexpr size_t GB_LDS = GB_STAGE_OFF + 4 * GB_STAGE_WAVE;   // 163,456 B
+#endif
+static_assert(GB_STAGE_OFF + 4 * GB_STAGE_WAVE <= 163840 - 384, "LDS budget");
+
+struct GbrGeom {
+    int tiles_x, tiles_y;     // 16 x 16 pixel tiles per row / column
+    int tiles_p;              // pixel tiles = tiles_x * tiles_y * B
+    int nr;                   // channel blocks (128 columns) per work item
+    int items;                // tiles_p * (N / 128 / nr); item = range * tiles_p + pixel tile (pixel tile fastest: the
+                              // workgroups of an XCD sweep the same weights at the same time)
+};
+
+#ifndef GB_PD
+#define GB_PD 6
+#endif
+#ifndef GB_PDC
+#define GB_PDC 3
+#endif
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+conv_gb_resident(const GbrParams p, const GbrGeom g) {
+    constexpr int PH = GB_PH, HW = 18, HP = 324;
+    constexpr int PD = GB_PD, PDC = GB_PDC;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 15, cg = lane >> 4;
+
+    // persistent walk: XCD x owns a contiguous range of items, its workgroups take consecutive items of it
+    const int slots = gridDim.x >> 3, xcd = blockIdx.x & 7;
+    const int tq = g.items >> 3, tr = g.items & 7;
+    const int cnt = tq + (xcd < tr ? 1 : 0);
+    const int base = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+
+    // ---- lane constants of the sweep ----
+    // fp16 fragment of pixel row i, tap (dy, dx), chunk c: plane (c, piece cg), pixel (i + dy) * 18 + dx + px
+    const char* const FL0 = smem + (cg * PH + px) * 16;                          // chunks 0, 1
+    const char* const FL1 = FL0 + 2 * 4 * PH * 16;                               // chunks 2, 3 (ds offsets are 16 bits)
+    // fp6 piece of the lane: kind = cg & 1 (h6 | l6) of the pair's even tap (cg < 2) or odd tap
+    // A pair's pieces are the even tap's for lane groups 0, 1 and the odd tap's for 2, 3: the odd tap's halo pixel is 1 (next
+    // column), 16 (next row: 18 - 2) or, from tap 8 to tap 0 of the next chunk, one chunk minus 38 pixels further; with that
+    // difference in the lane pointer the pair's own position is an immediate offset of the ds_read
+    const char* const XL = smem + GB_F_BYTES + ((cg & 1) * 3 * PH + px) * 8;
+    const char* const XLd[3] = {XL + (cg < 2 ? 0 : 1 * 8), XL + (cg < 2 ? 0 : 16 * 8), XL + (cg < 2 ? 0 : (6 * PH - 38) * 8)};
+    const char* const SL = smem + GB_F_BYTES + GB_X_BYTES + (cg & 1) * PH + px;
+    const char* const SLd[3] = {SL + (cg < 2 ? 0 : 1), SL + (cg < 2 ? 0 : 16), SL + (cg < 2 ? 0 : 2 * PH - 38)};
+    char* const stage = smem + GB_STAGE_OFF + wq * GB_STAGE_WAVE;
+    // weight rows of the wave (conv_sw.hip): column block j -> rows 64 * (wq >> 1) + 16 * (wq & 1) + 32 * j + px of the tile
+    constexpr int CIN = 128, BKC = 32;
+    int b_voff[2], b_xoff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row_ = (((wq >> 1) * 64 + (wq & 1) * 16 + 32 * j + px) * CIN) * 4;
+        b_voff[j] = row_ + 16 * cg;
+        b_xoff[j] = row_ + 64 + 32 * (cg & 1);                                   // l6 piece (even groups) | h6 piece (odd)
+    }
+    const unsigned w_tap_bytes = (unsigned)((size_t)p.N * CIN * sizeof(float));
+    // lane offset of the fp6 piece incl. the distance of the lane's tap from the pair's smaller weight offset: the odd tap is
+    // one tap further (normal pair), or the EVEN tap is 8 taps minus one chunk further (tap 8 | tap 0 of the next chunk)
+    int b_xoffn[2], b_xoffw[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        b_xoffn[j] = b_xoff[j] + (cg < 2 ? 0 : (int)w_tap_bytes);
+        b_xoffw[j] = b_xoff[j] + (cg < 2 ? (int)(8u * w_tap_bytes) - BKC * 4 : 0);
+    }
+    const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.wt), 0, (int)(9u * w_tap_bytes), 0x00020000);
+#define GB_BUFLD(voff, soff) __builtin_amdgcn_raw_buffer_load_b128(rs_wt, voff, (int)(soff), 0)
+
+    f32x4 acc[16][2];
+    i32x4 bE[2], bO[2], xE[2], xO[2], nbE[2], nbO[2], nxE[2], nxO[2];
+    i32x4 fa[16], fb[16];
+    i32x2 xa[16][3];
+    int xs[16];
+
+#ifdef MSR_GB_STAMPS
+    unsigned* const dbg = reinterpret_cast<unsigned*>(smem + 163840 - 384) + wq * 24;
+    int dbg_n = 0;
+#define GB_STAMP() if (blockIdx.x == 8 && lane == 0 && dbg_n < 24) dbg[dbg_n++] = (unsigned)__builtin_amdgcn_s_memtime();
+#else
+#define GB_STAMP()
+#endif
+
+    for (int it = blockIdx.x >> 3; it < cnt; it += slots) {
+        const int item = base + it;
+        const int rng = item / g.tiles_p;
+        int tmi = item - rng * g.tiles_p;
+        const int tx0 = (tmi % g.tiles_x) << 4;
+        tmi /= g.tiles_x;
+        const int ty0 = (tmi % g.tiles_y) << 4;
+        const int b0 = tmi / g.tiles_y;
+        const int nt0 = rng * g.nr;
+
+        GB_STAMP()
+        __syncthreads();                       // the previous item's sweep has left the planes and the stage lines
+        // ================= phase 1a: the 20 x 20 patch of the nearest-resized 2-channel mask (zero outside the image) =========
+        {
+            float2* const patch = reinterpret_cast<float2*>(smem + GB_STAGE_OFF);
+            for (int q = tid; q < 400; q += 256) {
+                const int py = q / 20, pxx = q - py * 20;
+                const int y = ty0 - 2 + py, x = tx0 - 2 + pxx;
+                float2 v = make_float2(0.f, 0.f);
+                if (y >= 0 && y < p.r && x >= 0 && x < p.r)
+                    v = *reinterpret_cast<const float2*>(p.src + (((size_t)b0 * p.S + (y * p.f + p.o)) * p.S + (x * p.f + p.o)) * 2);
+                patch[q] = v;
+            }
+        }
+        __syncthreads();
+        // ================= phase 1b: embedding halo -> F / X / SC planes; wave = chunk ======================================
+        // E[ch][pixel] = bias[ch] + sum_k We[k][ch] * mask[pixel][k] on v_mfma_f32_32x32x2_f32 (exact fp32: the fmaf chain in
+        // k = (ky, kx, c) order, bias first), k = 2 * tap + c: 9 MFMAs per tile of 32 channels x 32 pixels.  A lane of the
+        // 32 x 32 result holds HALF of a pixel's 32 channels (rows 8q + 4h + r, h = lane >> 5); two tiles (pixels A, B) and
+        // one v_permlane32_swap per register leave ALL 32 channels of pixel 64 * pair + lane in the lane, which is what the
+        // fp6 converter wants (v_cvt_scalef32_2xpk16_fp6_f32: 32 values -> one 24-byte k-block, element 2t = a[t],
+        // 2t + 1 = b[t]; tools/gpu_diag_gbr.hip).  Position e of a chunk is therefore channel GBR_PERM(e) =
+        // 8 * (e >> 3) + 4 * (e & 1) + ((e >> 1) & 3); the gamma|beta weights are uploaded in the same order.
+        {
+            const float* const patch = reinterpret_cast<const float*>(smem + GB_STAGE_OFF);
+            const int h = lane >> 5;
+            // A operand of MFMA step s = We[k = 2 s + h][32 wq + (lane & 31)] (HWIO [3][3][2][128]: k = 2 * tap + c), and the
+            // bias of the lane's 16 result rows; reloaded per item (L2 hits) so that they do not occupy registers in the sweep
+            float ewt[9], ebias[16];
+#pragma unroll
+            for (int sT = 0; sT < 9; ++sT) ewt[sT] = p.we[(2 * sT + h) * 128 + 32 * wq + (lane & 31)];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) ebias[t] = p.be[32 * wq + 8 * (t >> 2) + 4 * h + (t & 3)];
+            for (int pair = 0; pair < 6; ++pair) {
+                f32x16 accT[2];
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl) {
+                    if (pair == 5 && tl == 1) break;                             // pixels 352.. do not exist
+                    int hq = 64 * pair + 32 * tl + (lane & 31);
+                    hq = hq < HP ? hq : HP - 1;
+                    const int hy = (hq * 3641) >> 16;                            // / 18 for 0 <= hq < 324
+                    const int hx = hq - hy * HW;
+                    const float* const pp = patch + ((hy * 20 + hx) * 2 + h);
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) accT[tl][t] = ebias[t];
+#pragma unroll
+                    for (int sT = 0; sT < 9; ++sT)
+                        accT[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(ewt[sT], pp[((sT / 3) * 20 + sT % 3) * 2], accT[tl], 0, 0, 0);
+                }
+                // lane l < 32: (lo, hi) = tile A's two channel halves of pixel 64 pair + l; l >= 32: tile B's, pixel 64 pair + l
+                float lo[16], hi[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    // (scalar temporaries: __builtin_bit_cast applied to a vector ELEMENT reads element 0, hipcc 7.2)
+                    const float fa_ = accT[0][t], fb_ = accT[1][t];
+                    const unsigned ya = pair == 5 ? 0u : __builtin_bit_cast(unsigned, fb_);
+                    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, fa_), ya, false, false);
+                    const unsigned r0 = r[0], r1 = r[1];
+                    lo[t] = __builtin_bit_cast(float, r0);
+                    hi[t] = __builtin_bit_cast(float, r1);
+                }
+                const int hp = 64 * pair + lane;
+                const bool live = hp < HP;
+                const int hq = live ? hp : HP - 1;
+                const int hy = (hq * 3641) >> 16, hx = hq - hy * HW;
+                const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
+                const bool inside = y >= 0 && y < p.r && x >= 0 && x < p.r;      // outside: the conv's zero padding, not relu(bias)
+                float amax = 0.f;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    float a = lo[t] > 0.f ? lo[t] : 0.f, b = hi[t] > 0.f ? hi[t] : 0.f;
+                    a = inside ? a : 0.f;
+                    b = inside ? b : 0.f;
+                    a = a > 65504.f ? 65504.f : a;                               // fp16's range (as msr_store_f16c4_dev)
+                    b = b > 65504.f ? 65504.f : b;
+                    lo[t] = a;
+                    hi[t] = b;
+                    amax = fmaxf(amax, fmaxf(a, b));
+                }
+                const int eb = msr_block_e8m0_dev(amax);
+                const float s_hi = __builtin_bit_cast(float, eb << 23);
+                const float s_lo = __builtin_bit_cast(float, (eb - 11) << 23);
+                f32x16 va, vb, la, lb;
+                f16x8 hv[4];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const _Float16 ha = (_Float16)lo[t], hb = (_Float16)hi[t];
+                    hv[t >> 2][2 * (t & 3)] = ha;                                // position 2t = lo[t], 2t + 1 = hi[t]
+                    hv[t >> 2][2 * (t & 3) + 1] = hb;
+                    va[t] = lo[t];
+                    vb[t] = hi[t];
+                    la[t] = lo[t] - (float)ha;
+                    lb[t] = hi[t] - (float)hb;
+                }
+                // v_cvt_scalef32_2xpk16_fp6_f32 through inline asm with an EARLY-CLOBBER result: the builtin lets hipcc 7.2 put
+                // the 6 result registers on top of the first source (v[34:39] <- v[34:49], ...), and the hardware then reads
+                // clobbered inputs (measured: the h6 piece came out partly wrong, tools/gpu_debug_gbr.py)
+                i32x6 h6, l6;
+                asm volatile("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(h6) : "v"(va), "v"(vb), "v"(s_hi));
+                asm volatile("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(l6) : "v"(la), "v"(lb), "v"(s_lo));
+                if (live) {
+                    char* const fp = smem + (wq * 4 * PH + hp) * 16;
+#pragma unroll
+                    for (int pc = 0; pc < 4; ++pc) *reinterpret_cast<f16x8*>(fp + pc * PH * 16) = hv[pc];
+                    char* const xp = smem + GB_F_BYTES + (wq * 6 * PH + hp) * 8;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        *reinterpret_cast<i32x2*>(xp + j * PH * 8) = i32x2{h6[2 * j], h6[2 * j + 1]};
+                        *reinterpret_cast<i32x2*>(xp + (3 + j) * PH * 8) = i32x2{l6[2 * j], l6[2 * j + 1]};
+                    }
+                    unsigned char* const sp = reinterpret_cast<unsigned char*>(smem) + GB_F_BYTES + GB_X_BYTES + wq * 2 * PH + hp;
+                    sp[0] = (unsigned char)eb;
+                    sp[PH] = (unsigned char)(eb - 11);
+                }
+            }
+        }
+        __syncthreads();
+        GB_STAMP()
+
+        // ================= phase 2: sweep the item's channel blocks over the resident halo ====================================
+        // K-step T of a body (CB = its first chunk, 0 or 2): chunk (CB + T / 9) & 3, tap T % 9; T = 18, 19 are the first two
+        // steps of whatever comes next (the other body of this channel block, or the first body of the next block)
+#define GB_CH(CB, T) (((CB) + (T) / 9) & 3)
+#define GB_TAP(T) ((((T) % 9) / 3) * HW + ((T) % 9) % 3)
+#define GB_RD_F(dst, CB, T, i)                                                                    \
+    dst = *reinterpret_cast<const i32x4*>((GB_CH(CB, T) >> 1 ? FL1 : FL0) +                      \
+                                          ((GB_CH(CB, T) & 1) * 4 * PH + (i) * HW + GB_TAP(T)) * 16)
+        // per-lane pointers of a pair's fp6 pieces and scales: lane groups 0, 1 read the even tap, 2, 3 the odd one
+#define GB_DSEL(TE) ((TE) % 9 == 8 ? 2 : (((TE) % 9) % 3 == 2 ? 1 : 0))
+#define GB_XP(CB, TE) (XLd[GB_DSEL(TE)] + (GB_CH(CB, TE) * 6 * PH + GB_TAP(TE)) * 8)
+#define GB_SP(CB, TE) (SLd[GB_DSEL(TE)] + GB_CH(CB, TE) * 2 * PH + GB_TAP(TE))
+#define GB_RD_X(k, XP, SP, i)                                                                     \
+    {                                                                                            \
+        xa[k][0] = *reinterpret_cast<const i32x2*>((XP) + (i) * HW * 8);                          \
+        xa[k][1] = *reinterpret_cast<const i32x2*>((XP) + (i) * HW * 8 + PH * 8);                 \
+        xa[k][2] = *reinterpret_cast<const i32x2*>((XP) + (i) * HW * 8 + 2 * PH * 8);             \
+        xs[k] = *reinterpret_cast<const unsigned char*>((SP) + (i) * HW);                         \
+    }
+        // weights of K-step T of the body: byte offset from the channel block's first row
+#define GB_WSOFF(CB, T) ((T) < 18 ? w_cur + (unsigned)(((CB) + (T) / 9) * (BKC * 4)) + (unsigned)((T) % 9) * w_tap_bytes \
+                                  : w_after + (unsigned)((T) - 18) * w_tap_bytes)
+#define GB_LOAD_B(dstE, dstO, dxE, dxO, CB, T, j)                                                 \
+    {                                                                                            \
+        dstE[j] = GB_BUFLD(b_voff[j], GB_WSOFF(CB, T));                                          \
+        dstO[j] = GB_BUFLD(b_voff[j], GB_WSOFF(CB, (T) + 1));                                    \
+        /* both 16-byte halves of the lane's fp6 piece, from the even tap's row (lane groups 0, 1) or the odd tap's (2, 3);  \
+           the scalar offset is the smaller of the two taps' (the other one's excess rides in the lane offset) */ \
+        const unsigned lo_ = (T) % 9 == 8 && (T) < 18 ? GB_WSOFF(CB, (T) + 1) : GB_WSOFF(CB, T); \
+        const int xo_ = (T) % 9 == 8 && (T) < 18 ? b_xoffw[j] : b_xoffn[j];                      \
+        dxE[j] = GB_BUFLD(xo_, lo_);                                                             \
+        dxO[j] = GB_BUFLD(xo_ + 16, lo_);                                                        \
+    }
+#define GB_F16(v) __builtin_bit_cast(f16x8, v)
+#define GB_CAT8(lo, hi) __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)
+        // Phase E of pair U: tap 2U, fragments fa; requests fa ahead, then fb of tap 2U + 1; the next pair's weights
+#define GB_PHASE_E(CB, U)                                                                         \
+    {                                                                                            \
+        constexpr int T = 2 * (U);                                                               \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                         \
+            if (i + PD < 16) GB_RD_F(fa[(i + PD) & 15], CB, T, (i + PD) & 15);                   \
+            else GB_RD_F(fb[(i + PD) & 15], CB, T + 1, (i + PD) & 15);                           \
+            if (i == 0) GB_LOAD_B(nbE, nbO, nxE, nxO, CB, T + 2, 0)                              \
+            if (i == 8) GB_LOAD_B(nbE, nbO, nxE, nxO, CB, T + 2, 1)                              \
+            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(GB_F16(bE[0]), GB_F16(fa[i]), acc[i][0], 0, 0, 0); \
+            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(GB_F16(bE[1]), GB_F16(fa[i]), acc[i][1], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+        }                                                                                        \
+    }
+    // Phase O: tap 2U + 1, fragments fb; requests fb ahead, then the first fp6 pieces of the pair
+#define GB_PHASE_O(CB, U)                                                                         \
+    {                                                                                            \
+        constexpr int T = 2 * (U) + 1;                                                           \
+        const char* const xp_ = GB_XP(CB, T - 1);                                                \
+        const char* const sp_ = GB_SP(CB, T - 1);                                                \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                         \
+            if (i + PD < 16) GB_RD_F(fb[(i + PD) & 15], CB, T, (i + PD) & 15);                   \
+            if (i >= 16 - PDC) GB_RD_X((i + PDC) & 15, xp_, sp_, (i + PDC) & 15)                 \
+            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(GB_F16(bO[0]), GB_F16(fb[i]), acc[i][0], 0, 0, 0); \
+            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(GB_F16(bO[1]), GB_F16(fb[i]), acc[i][1], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+        }                                                                                        \
+    }
+    // Phase C: the cross terms of taps 2U and 2U + 1 (block-scaled K = 128 fp6 MFMA, operands in registers 0..5, the block
+    // scales in byte 0 of the scale operands); requests the fp6 pieces ahead, then fa of the next pair's first tap
+#define GB_PHASE_C(CB, U)                                                                         \
+    {                                                                                            \
+        constexpr int T = 2 * (U);                                                               \
+        const i32x8 wq0_ = GB_CAT8(xE[0], xO[0]), wq1_ = GB_CAT8(xE[1], xO[1]);                  \
+        const char* const xp_ = GB_XP(CB, T);                                                    \
+        const char* const sp_ = GB_SP(CB, T);                                                    \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                         \
+            if (i + PDC < 16) GB_RD_X((i + PDC) & 15, xp_, sp_, (i + PDC) & 15)                  \
+            if (i >= 16 - PD) GB_RD_F(fa[(i + PD) & 15], CB, T + 2, (i + PD) & 15);              \
+            const i32x8 aq_ = {xa[i][0][0], xa[i][0][1], xa[i][1][0], xa[i][1][1], xa[i][2][0], xa[i][2][1], 0, 0}; \
+            acc[i][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wq0_, aq_, acc[i][0], 2, 2, 0, wq0_[6], 0, xs[i]); \
+            acc[i][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wq1_, aq_, acc[i][1], 2, 2, 0, wq1_[6], 0, xs[i]); \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+        }                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) { bE[j] = nbE[j]; bO[j] = nbO[j]; xE[j] = nxE[j]; xO[j] = nxO[j]; } \
+    }
+#define GB_PAIR(CB, U) GB_PHASE_E(CB, U) GB_PHASE_O(CB, U) GB_PHASE_C(CB, U)
+#define GB_BODY(CB) GB_PAIR(CB, 0) GB_PAIR(CB, 1) GB_PAIR(CB, 2) GB_PAIR(CB, 3) GB_PAIR(CB, 4) GB_PAIR(CB, 5) GB_PAIR(CB, 6) GB_PAIR(CB, 7) GB_PAIR(CB, 8)
+
+        // prologue of the sweep: the weights of taps 0 and 1 of the first channel block, the first PD pixel fragments
+        {
+            const unsigned w_cur = (unsigned)(nt0 * 128 * CIN) * 4u, w_after = w_cur;
+            GB_LOAD_B(bE, bO, xE, xO, 0, 0, 0)
+            GB_LOAD_B(bE, bO, xE, xO, 0, 0, 1)
+        }
+#pragma unroll
+        for (int i = 0; i < PD; ++i) GB_RD_F(fa[i], 0, 0, i);
+
+        for (int nt = nt0; nt < nt0 + g.nr; ++nt) {
+            const int n0 = nt * 128;
+            const unsigned w_cur = (unsigned)(n0 * CIN) * 4u;
+            const unsigned w_nxt = nt + 1 < nt0 + g.nr ? w_cur + 128u * CIN * 4u : w_cur;     // last block: re-reads its own (unused)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+            {
+                const unsigned w_after = w_cur + 2u * BKC * 4u;
+                GB_BODY(0)
+            }
+            // the epilogue's memory operands, requested a whole body ahead
+            const int x = tx0 + px;
+            const int ch = ((n0 + (wq >> 1) * 64) >> 1) + (wq & 1) * 16 + 4 * cg;     // first of the lane's 4 output channels
+            const int cb0 = n0 + (wq >> 1) * 64 + (wq & 1) * 16 + 4 * cg;             // its gamma column (beta: + 32)
+            float4 xin[16];
+            float4 gq4, bq4, mq4, sq4;
+            {
+                const unsigned w_after = w_nxt;
+                GB_PAIR(2, 0) GB_PAIR(2, 1) GB_PAIR(2, 2) GB_PAIR(2, 3) GB_PAIR(2, 4) GB_PAIR(2, 5) GB_PAIR(2, 6)
+                {   // ~2 tap pairs (4000 cycles) before their use
+                    const float* const abase = p.aux + (size_t)b0 * p.aux_pb + (x >> p.aux_shift) * p.aux_px + ch;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        xin[i] = *reinterpret_cast<const float4*>(abase + ((ty0 + i) >> p.aux_shift) * p.aux_py);
+                    gq4 = *reinterpret_cast<const float4*>(p.bias + cb0);
+                    bq4 = *reinterpret_cast<const float4*>(p.bias + cb0 + 32);
+                    mq4 = *reinterpret_cast<const float4*>(p.mean + ch);
+                    sq4 = *reinterpret_cast<const float4*>(p.stdv + ch);
+                }
+                GB_PAIR(2, 7) GB_PAIR(2, 8)
+            }
+            // ---- SPADE epilogue: acc[i][0] = gamma, acc[i][1] = beta of channels ch .. ch + 3 at pixel (ty0 + i, x) ----
+            {
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const float gq[4] = {gq4.x, gq4.y, gq4.z, gq4.w}, bq[4] = {bq4.x, bq4.y, bq4.z, bq4.w};
+                const float mq[4] = {mq4.x, mq4.y, mq4.z, mq4.w};
+                const float rs[4] = {1.f / sq4.x, 1.f / sq4.y, 1.f / sq4.z, 1.f / sq4.w};
+                const int half = wq & 1;
+                // the lane's 16 bytes of the pixel's chunk line: fp16 of 8 channels (lane groups 0, 1), h8 / l8 of the 16 (2 / 3)
+                const int doff = cg < 2 ? half * 8 + 4 * cg : (cg == 2 ? 16 + half * 4 : 24 + half * 4);
+                unsigned* const obase = reinterpret_cast<unsigned*>(p.out + (size_t)p.out_off + (size_t)b0 * p.out_pb +
+                                                                    x * p.out_px + (ch & ~31)) + doff;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    char* const line = stage + (i & 1) * (16 * GB_LINE) + px * GB_LINE;
+                    const float xq[4] = {xin[i].x, xin[i].y, xin[i].z, xin[i].w};
+                    float v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float normalized = (xq[k] - mq[k]) * rs[k];
+                        const float t = (acc[i][0][k] + gq[k]) * normalized + (acc[i][1][k] + bq[k]);
+                        const float u = t >= 0.f ? t : t * p.slope;
+                        v[k] = u > 65504.f ? 65504.f : (u < -65504.f ? -65504.f : u);
+                    }
+                    const h2 a = {(_Float16)v[0], (_Float16)v[1]}, b = {(_Float16)v[2], (_Float16)v[3]};
+                    unsigned h8 = 0, l8 = 0;
+                    h8 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], h8, false);
+                    h8 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], h8, true);
+                    l8 = __builtin_amdgcn_cvt_pk_fp8_f32((v[0] - (float)a[0]) * 2048.f, (v[1] - (float)a[1]) * 2048.f, l8, false);
+                    l8 = __builtin_amdgcn_cvt_pk_fp8_f32((v[2] - (float)b[0]) * 2048.f, (v[3] - (float)b[1]) * 2048.f, l8, true);
+                    *reinterpret_cast<uint2*>(line + 8 * cg) = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+                    *reinterpret_cast<unsigned*>(line + 32 + 4 * cg) = h8;
+                    *reinterpret_cast<unsigned*>(line + 48 + 4 * cg) = l8;
+                    asm volatile("" ::: "memory");          // the pieces were written through other types
+                    const uint4 q = *reinterpret_cast<const uint4*>(line + 16 * cg);
+                    asm volatile("" ::: "memory");
+                    *reinterpret_cast<uint4*>(obase + (size_t)(ty0 + i) * p.out_py) = q;
+                }
+            }
+        }
+        GB_STAMP()
+    }
+#ifdef MSR_GB_STAMPS
+    if (blockIdx.x == 8 && lane == 0)
+        for (int k = 0; k + 1 < dbg_n; ++k) printf("gbr wave %d stamp %2d: %7u cycles\n", wq, k, dbg[k + 1] - dbg[k]);
+#endif
+#undef GB_STAMP
+#undef GB_BUFLD
+#undef GB_CH
+#undef GB_TAP
+#undef GB_RD_F
+#undef GB_XP
+#undef GB_DSEL
+#undef GB_SP
+#undef GB_RD_X
+#undef GB_WSOFF
+#undef GB_LOAD_B
+#undef GB_F16
+#undef GB_CAT8
+#undef GB_PHASE_E
+#undef GB_PHASE_O
+#undef GB_PHASE_C
+#undef GB_PAIR
+#undef GB_BODY
+}
+
+hipError_t conv_gbr_init() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gb_resident), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)GB_LDS);
+}
+
+// Work decomposition: a work item = one 16 x 16 pixel tile x `nr` channel blocks; the N / 128 blocks of a pixel tile are cut
+// into the fewest ranges (a power of two) that give every CU an item.  Returns 0 if the layer is not one for this kernel.
+int conv_gbr_ranges(int B, int r, int N) {
+    static const bool off = std::getenv("MSR_GBR") && std::atoi(std::getenv("MSR_GBR")) == 0;
+    if (off || r < 32 || (r & (r - 1)) || N % 128) return 0;
+    const int tiles_p = B * (r / 16) * (r / 16), tiles_n = N / 128;
+    int ranges = 1;
+    while (tiles_p * ranges < 256 && ranges * 2 <= tiles_n && tiles_n % (ranges * 2) == 0) ranges *= 2;
+    if (tiles_p * ranges < 128) return 0;               // too few items even at one block per item
+    if (tiles_n / ranges < 2 && tiles_p * ranges < 256) return 0;
+    return ranges;
+}
+
+hipError_t launch_conv_gbr(const GbrParams& p, int ranges, hipStream_t s) {
+    if (ranges < 1 || p.r < 16 || (p.r & (p.r - 1)) || p.N % 128 || (p.N / 128) % ranges || p.out_split != 4 || !p.src || !p.we || !p.be || !p.wt || !p.aux || !p.mean || !p.stdv || !p.out)
+        return hipErrorInvalidValue;
+    if (p.f < 1 || p.S != p.r * p.f || p.out_px % 32) return hipErrorInvalidValue;
+    GbrGeom g;
+    g.tiles_x = p.r / 16;
+    g.tiles_y = p.r / 16;
+    g.tiles_p = g.tiles_x * g.tiles_y * p.B;
+    g.nr = p.N / 128 / ranges;
+    g.items = g.tiles_p * ranges;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidValue;
+        n_cu = prop.multiProcessorCount & ~7;
+        if (n_cu < 8) n_cu = 8;
+    }
+    const int grid = g.items < n_cu ? ((g.items + 7) & ~7) : n_cu;
+    conv_gb_resident<<<grid, 256, GB_LDS, s>>>(p, g);
+    return hipGetLastError();
+}
+
+}  // namespace msr

@@ -273,6 +273,33 @@ void conv_walk_pick(int tiles_m, int tiles_n, int* walk_pb, int* walk_nb);
         tmi_ = blk_ * (g).walk_pb + jp_;                                                         \
     }
 
+// conv_gbr.hip: one SPADE layer's modulation path in one kernel for the launches that fill the chip — nearest resize of the
+// call's 2-channel input + mask-embedding conv + ReLU (spade.py:17-18) computed per 16 x 16 pixel tile into LDS (f16c6
+// operand), the gamma|beta conv (spade.py:19-20) swept over it for all output channels, SPADE epilogue (spade.py:21-24).
+struct GbrParams {
+    const float* src;       // [B, S, S, 2] the call's input
+    const float* we;        // mask-embedding conv kernel, HWIO [3][3][2][128]
+    const float* be;        // its bias [128]
+    int S, f, o;            // source size; nearest resize to r x r: source index = t * f + o (f = S / r, o = f / 2)
+    const float* wt;        // gamma|beta weights: PREC_F16C6 image of [9][N][128] (columns interleaved 32 gamma | 32 beta)
+    const float* bias;      // [N] in GEMM column order
+    const float* aux;       // x, the tensor being normalised: [B, r >> aux_shift, r >> aux_shift, N / 2] dense
+    int aux_px, aux_py, aux_pb, aux_shift;
+    const float* mean;      // [N / 2]
+    const float* stdv;      // [N / 2] sqrt(var + eps)
+    float* out;             // zero-bordered input of the consumer conv (f16c chunk image)
+    int out_px, out_py, out_pb, out_off;
+    int out_split;          // 4: the f16c chunk image (PREC_F16C consumer)
+    float slope;
+    int B, r, N;
+};
+hipError_t conv_gbr_init();
+// > 0: the layer runs conv_gb_resident with the channel blocks of a pixel tile cut into that many work items; 0: not a layer
+// for it (MSR_GBR=0 switches the kernel off: A/B runs)
+int conv_gbr_ranges(int B, int r, int N);
+// ranges: work items per pixel tile (a divisor of N / 128); the planner passes conv_gbr_ranges()
+hipError_t launch_conv_gbr(const GbrParams& p, int ranges, hipStream_t s);
+
 hipError_t conv_igemm_init();   // sets dynamic-LDS attributes once
 // conv_sw.hip: PREC_F16C whole-tile launches as one software-pipelined wave per SIMD.  launch_conv_igemm sends it the
 // long-K main convs (bias / residual epilogues, Cin % 128 == 0); MSR_F16C_SW = 0 keeps everything on the ping-pong kernel,

@@ -339,6 +339,30 @@ def conv3x3_f16c(ctx: OpContext, x_img: torch.Tensor, w_img: torch.Tensor, wexp:
     return out
 
 
+GBR_PERM = [8 * (e >> 3) + 4 * (e & 1) + ((e >> 1) & 3) for e in range(32)]   # csrc/conv_gbr.hip: position e <- channel
+
+
+def gbr_weight_image(w_kl: torch.Tensor) -> torch.Tensor:
+    """gamma|beta weights [9][N][128] (kernel layout, spade_layout rows) -> the image conv_gb_resident reads: the f16c6 image
+    with the input channels of every 32-chunk in the kernel's position order."""
+    idx = torch.tensor([32 * c + GBR_PERM[e] for c in range(w_kl.shape[2] // 32) for e in range(32)], device=w_kl.device)
+    return f16c6_weight_image(w_kl[:, :, idx].contiguous())[0]
+
+
+def spade_gbr(ctx: OpContext, src: torch.Tensor, we: torch.Tensor, be: torch.Tensor, w_img: torch.Tensor, bias: torch.Tensor,
+              r: int, x: torch.Tensor, aux_shift: int, mean: torch.Tensor, std: torch.Tensor) -> torch.Tensor:
+    """One launch of conv_gb_resident (msr_op_spade_gbr): resize + mask embedding + gamma|beta conv + SPADE epilogue;
+    returns the zero-bordered f16c image [B, r + 2, r + 2, C] (float32 storage; f16c_decode reads it)."""
+    B, S = src.shape[0], src.shape[1]
+    N = w_img.shape[1]
+    out = torch.zeros((B, r + 2, r + 2, N // 2), dtype=torch.float32, device=src.device)
+    rc = ctx.lib.msr_op_spade_gbr(ctx.h, src.data_ptr(), S, we.data_ptr(), be.data_ptr(), w_img.data_ptr(), bias.data_ptr(),
+                                  out.data_ptr(), B, r, N, x.data_ptr(), aux_shift, mean.data_ptr(), std.data_ptr(),
+                                  torch.cuda.current_stream(src.device).cuda_stream)
+    _lib.raise_for(ctx.lib, ctx.h, rc, "msr_op_spade_gbr")
+    return out
+
+
 def f16c_decode(img: torch.Tensor):
     """f16c activation image (float32 storage [..., C]) -> (hi, h8, lo8) as float64 tensors [..., C]."""
     shp = img.shape

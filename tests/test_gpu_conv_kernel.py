@@ -438,3 +438,43 @@ def test_f16c_convs_under_the_other_kernel_dispatch(mode):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
                         "f16c and not other_kernel_dispatch"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("B,S,r,C,shift", [(8, 128, 32, 1024, 1), (2, 256, 64, 128, 0), (8, 64, 64, 64, 1), (3, 512, 128, 64, 1)])
+def test_spade_layer_resident_kernel(ctx, B, S, r, C, shift):
+    """conv_gb_resident (csrc/conv_gbr.hip): nearest resize + mask-embedding conv + ReLU + gamma|beta conv + SPADE epilogue in
+    one launch, against the float64 chain of the same ops (spade.py:17-24, blocks.py:30-34).  The products are f16c6
+    (fp16 main term + fp6 cross pieces): <= 2e-4 of the output's range, like the f16c kernel's SPADE test; the written
+    image is the consumer's f16c chunk image (hi = fp16 of the value, hi + lo8 ~ 15 bits, h8 = e4m3 of it), border zero."""
+    from moonsuperresolution_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(1000 * B + r + C)
+    src = (torch.rand((B, S, S, 2), generator=g) - 0.5).cuda()
+    we = (torch.randn((3, 3, 2, 128), generator=g) / 3).cuda()
+    be = (0.1 * torch.randn(128, generator=g)).cuda()
+    wg = (torch.randn((3, 3, 128, C), generator=g) / 34).cuda()
+    wb_ = (torch.randn((3, 3, 128, C), generator=g) / 34).cuda()
+    bg, bb = torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+    x = (3 + 2 * torch.randn((B, r >> shift, r >> shift, C), generator=g)).cuda()
+    mean = x.mean((0, 1, 2)).contiguous()
+    std = torch.sqrt(x.var((0, 1, 2), unbiased=False) + 1e-5).contiguous()
+    w, bias = ops.spade_layout(wg, wb_, bg, bb)
+    wimg = ops.gbr_weight_image(w)
+    f = S // r
+    mask = src[:, f // 2::f, f // 2::f][:, :r, :r]                       # tf.image.resize(method="nearest"), half-pixel centres
+    e = torch.relu(ref_conv(mask, we, be, 1))
+    xr = x.double().cpu()
+    if shift:
+        xr = xr.repeat_interleave(2, 1).repeat_interleave(2, 2)
+    v = ref_conv(e, wg, bg, 1) * ((xr - mean.double().cpu()) / std.double().cpu()) + ref_conv(e, wb_, bb, 1)
+    want = torch.where(v >= 0, v, 0.2 * v)
+    y = ops.spade_gbr(ctx, src, we, be, wimg, bias, r, x, shift, mean, std)
+    full = ops.f16c_decode(y)
+    hi, h8, lo8 = (t.cpu()[:, 1:-1, 1:-1] for t in full)
+    err = rel_linf((hi + lo8).numpy(), want.numpy())
+    print(f"spade layer, resident kernel B={B} S={S} r={r} C={C}: rel L-inf vs float64 {err:.3e}")
+    assert err <= 2e-4
+    scale = float(want.abs().max())
+    assert float((hi - want).abs().max()) <= (2.0 ** -11 + 2e-4) * scale
+    assert float(((h8 - want).abs() / want.abs().clamp_min(2.0 ** -6)).max()) <= 2.0 ** -4 * 1.01 + 2e-3
+    assert float(full[0][:, 0].abs().max()) == 0 and float(full[1][:, :, -1].abs().max()) == 0 and \
+        float(full[0][:, -1].abs().max()) == 0 and float(full[2][:, :, 0].abs().max()) == 0        # the border stays zero
