@@ -135,8 +135,10 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
     unsigned* const dbg = reinterpret_cast<unsigned*>(smem + 163840 - 384) + wq * 24;
     int dbg_n = 0;
 #define GB_STAMP() if (blockIdx.x == 8 && lane == 0 && dbg_n < 24) dbg[dbg_n++] = (unsigned)__builtin_amdgcn_s_memtime();
+#define GB_STAMP2() if (MSR_GB_STAMPS >= 2) GB_STAMP()
 #else
 #define GB_STAMP()
+#define GB_STAMP2()
 #endif
 
     for (int it = blockIdx.x >> 3; it < cnt; it += slots) {
@@ -150,20 +152,45 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
         const int nt0 = rng * g.nr;
 
         GB_STAMP()
+        // Phase 1 operands (wave = chunk): A operand of MFMA step s = We[k = 2 s + h][32 wq + (lane & 31)] (HWIO [3][3][2][128]:
+        // k = 2 * tap + c) and the bias of the lane's 16 result rows.  Requested before the barrier, reloaded per item (L2 hits)
+        // so that they do not occupy registers in the sweep.
+        // phase 1's lane arithmetic (tile pixel -> patch address, halo pixel -> plane address, ...) is invariant across the
+        // items of the persistent loop: hoisted out of it, those ~40 values stay live through the sweep and spill to scratch
+        // (5 exposed scratch loads per pair of tiles: phase 1 ran 3x longer).  An opaque copy of the lane id keeps them local.
+        int lane1 = lane;
+        asm volatile("" : "+v"(lane1));
+        const int h = lane1 >> 5;
+        float ewt[9];
+        f32x16 ebias;
+#pragma unroll
+        for (int sT = 0; sT < 9; ++sT) ewt[sT] = p.we[(2 * sT + h) * 128 + 32 * wq + (lane1 & 31)];
+#pragma unroll
+        for (int t = 0; t < 16; t += 4) {
+            const float4 b4 = *reinterpret_cast<const float4*>(p.be + 32 * wq + 8 * (t >> 2) + 4 * h);
+            ebias[t] = b4.x; ebias[t + 1] = b4.y; ebias[t + 2] = b4.z; ebias[t + 3] = b4.w;
+        }
+        // the 20 x 20 patch of the nearest-resized 2-channel mask (zero outside the image): requested before the barrier too
+        float2 pv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = tid + 256 * u;
+            const int py = q / 20, pxx = q - py * 20;
+            const int y = ty0 - 2 + py, x = tx0 - 2 + pxx;
+            pv[u] = make_float2(0.f, 0.f);
+            if (q < 400 && y >= 0 && y < p.r && x >= 0 && x < p.r)
+                pv[u] = *reinterpret_cast<const float2*>(p.src + (((size_t)b0 * p.S + (y * p.f + p.o)) * p.S + (x * p.f + p.o)) * 2);
+        }
         __syncthreads();                       // the previous item's sweep has left the planes and the stage lines
-        // ================= phase 1a: the 20 x 20 patch of the nearest-resized 2-channel mask (zero outside the image) =========
+        GB_STAMP2()
+        // ================= phase 1a: the patch into LDS ========================================================================
         {
             float2* const patch = reinterpret_cast<float2*>(smem + GB_STAGE_OFF);
-            for (int q = tid; q < 400; q += 256) {
-                const int py = q / 20, pxx = q - py * 20;
-                const int y = ty0 - 2 + py, x = tx0 - 2 + pxx;
-                float2 v = make_float2(0.f, 0.f);
-                if (y >= 0 && y < p.r && x >= 0 && x < p.r)
-                    v = *reinterpret_cast<const float2*>(p.src + (((size_t)b0 * p.S + (y * p.f + p.o)) * p.S + (x * p.f + p.o)) * 2);
-                patch[q] = v;
-            }
+            patch[tid] = pv[0];
+            if (tid + 256 < 400) patch[tid + 256] = pv[1];
         }
         __syncthreads();
+        GB_STAMP2()
         // ================= phase 1b: embedding halo -> F / X / SC planes; wave = chunk ======================================
         // E[ch][pixel] = bias[ch] + sum_k We[k][ch] * mask[pixel][k] on v_mfma_f32_32x32x2_f32 (exact fp32: the fmaf chain in
         // k = (ky, kx, c) order, bias first), k = 2 * tap + c: 9 MFMAs per tile of 32 channels x 32 pixels.  A lane of the
@@ -172,98 +199,117 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
         // fp6 converter wants (v_cvt_scalef32_2xpk16_fp6_f32: 32 values -> one 24-byte k-block, element 2t = a[t],
         // 2t + 1 = b[t]; tools/gpu_diag_gbr.hip).  Position e of a chunk is therefore channel GBR_PERM(e) =
         // 8 * (e >> 3) + 4 * (e & 1) + ((e >> 1) & 3); the gamma|beta weights are uploaded in the same order.
+        // Software pipeline: the 18 MFMAs of pair p + 1 are issued before the conversion of pair p (an MFMA holds the vector
+        // issue for 8 of its 64 cycles: the ~200 VALU instructions of a conversion run beside them).
         {
             const float* const patch = reinterpret_cast<const float*>(smem + GB_STAGE_OFF);
-            const int h = lane >> 5;
-            // A operand of MFMA step s = We[k = 2 s + h][32 wq + (lane & 31)] (HWIO [3][3][2][128]: k = 2 * tap + c), and the
-            // bias of the lane's 16 result rows; reloaded per item (L2 hits) so that they do not occupy registers in the sweep
-            float ewt[9], ebias[16];
+            // B operands (patch values) of tile `tile_` (pixels 32 tile + (lane & 31), clamped): 9 LDS reads
+#define GB_EMB_LOADB(bv_, tile_)                                                                  \
+    {                                                                                            \
+        int hq_ = 32 * (tile_) + (lane1 & 31);                                                    \
+        hq_ = hq_ < HP ? hq_ : HP - 1;                                                           \
+        const int hy_ = (hq_ * 3641) >> 16;              /* / 18 for 0 <= hq < 324 */            \
+        const int hx_ = hq_ - hy_ * HW;                                                          \
+        const float* const pp_ = patch + ((hy_ * 20 + hx_) * 2 + h);                             \
+        _Pragma("unroll") for (int sT = 0; sT < 9; ++sT) bv_[sT] = pp_[((sT / 3) * 20 + sT % 3) * 2]; \
+    }
+            // the K-th of the 18 MFMAs of the NEXT pair (tile A step K >> 1 for even K, tile B for odd K), issued between the
+            // conversion steps of the current pair: an MFMA occupies the matrix pipe for 64 cycles and the vector issue for a
+            // few, so ~12 VALU instructions per MFMA run beside it
+#define GB_EMB_MFMA(K)                                                                            \
+    {                                                                                            \
+        if ((K) & 1) { if (nextB) nB = __builtin_amdgcn_mfma_f32_32x32x2f32(ewt[(K) >> 1], bvB[(K) >> 1], (K) >> 1 ? nB : ebias, 0, 0, 0); } \
+        else if (nextA) nA = __builtin_amdgcn_mfma_f32_32x32x2f32(ewt[(K) >> 1], bvA[(K) >> 1], (K) >> 1 ? nA : ebias, 0, 0, 0); \
+    }
+            // One pair: conversion of (tA, tB) = pixels 64 PAIR + lane, interleaved with the MFMAs of pair PAIR + 1 into (nA, nB).
+            // lane l < 32 gets tile A's two channel halves of its pixel, l >= 32 tile B's (v_permlane32_swap).
+#define GB_EMB_PAIR(PAIR)                                                                         \
+    {                                                                                            \
+        constexpr bool nextA = (PAIR) + 1 <= 5, nextB = (PAIR) + 1 <= 4;                          \
+        float bvA[9], bvB[9];                                                                    \
+        if (nextA) GB_EMB_LOADB(bvA, 2 * ((PAIR) + 1))                                            \
+        if (nextB) GB_EMB_LOADB(bvB, 2 * ((PAIR) + 1) + 1)                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        const int hp = 64 * (PAIR) + lane1;                                                       \
+        const bool live = hp < HP;                                                               \
+        const int hq = live ? hp : HP - 1;                                                       \
+        const int hy = (hq * 3641) >> 16, hx = hq - hy * HW;                                     \
+        const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;                                            \
+        /* relu, the conv's zero padding outside the image (not relu(bias)) and fp16's range (as msr_store_f16c4_dev) in \
+           one v_med3_f32: clamp to [0, top] with top = 0 for a pixel outside the image */     \
+        const float top = (y >= 0 && y < p.r && x >= 0 && x < p.r) ? 65504.f : 0.f;              \
+        float lo[16], hi[16];                                                                    \
+        float amax = 0.f;                                                                        \
+        _Pragma("unroll") for (int t = 0; t < 16; ++t) {                                         \
+            /* (scalar temporaries: __builtin_bit_cast applied to a vector ELEMENT reads element 0, hipcc 7.2) */ \
+            const float fa_ = tA[t], fb_ = tB[t];                                                \
+            const unsigned ya_ = (PAIR) == 5 ? 0u : __builtin_bit_cast(unsigned, fb_);           \
+            const auto r_ = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, fa_), ya_, false, false); \
+            const unsigned r0_ = r_[0], r1_ = r_[1];                                             \
+            lo[t] = __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, r0_), 0.f, top);           \
+            hi[t] = __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, r1_), 0.f, top);           \
+            amax = fmaxf(amax, fmaxf(lo[t], hi[t]));                                             \
+            if (t < 10) GB_EMB_MFMA(t)                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+        }                                                                                        \
+        const int eb = msr_block_e8m0_dev(amax);                                                 \
+        const float s_hi = __builtin_bit_cast(float, eb << 23);                                  \
+        const float s_lo = __builtin_bit_cast(float, (eb - 11) << 23);                           \
+        f32x16 va, vb, la, lb;                                                                   \
+        f16x8 hv[4];                                                                             \
+        _Pragma("unroll") for (int t = 0; t < 16; ++t) {                                         \
+            typedef _Float16 h2_ __attribute__((ext_vector_type(2)));                            \
+            const h2_ pk = {(_Float16)lo[t], (_Float16)hi[t]};                                   \
+            hv[t >> 2][2 * (t & 3)] = pk[0];             /* position 2t = lo[t], 2t + 1 = hi[t] */ \
+            hv[t >> 2][2 * (t & 3) + 1] = pk[1];                                                 \
+            va[t] = lo[t];                                                                       \
+            vb[t] = hi[t];                                                                       \
+            la[t] = lo[t] - (float)pk[0];                                                        \
+            lb[t] = hi[t] - (float)pk[1];                                                        \
+            if (t < 8) GB_EMB_MFMA(10 + t)                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+        }                                                                                        \
+        /* v_cvt_scalef32_2xpk16_fp6_f32 through inline asm with an EARLY-CLOBBER result: the builtin lets hipcc 7.2 put \
+           the 6 result registers on top of the first source (v[34:39] <- v[34:49], ...), and the hardware then reads    \
+           clobbered inputs (measured: the h6 piece came out partly wrong, tools/gpu_debug_gbr.py) */ \
+        i32x6 h6, l6;                                                                            \
+        asm volatile("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(h6) : "v"(va), "v"(vb), "v"(s_hi)); \
+        asm volatile("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(l6) : "v"(la), "v"(lb), "v"(s_lo)); \
+        if (live) {                                                                              \
+            char* const fp = smem + (wq * 4 * PH + hp) * 16;                                     \
+            _Pragma("unroll") for (int pc = 0; pc < 4; ++pc) *reinterpret_cast<f16x8*>(fp + pc * PH * 16) = hv[pc]; \
+            char* const xp = smem + GB_F_BYTES + (wq * 6 * PH + hp) * 8;                         \
+            _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                      \
+                *reinterpret_cast<i32x2*>(xp + j * PH * 8) = i32x2{h6[2 * j], h6[2 * j + 1]};    \
+                *reinterpret_cast<i32x2*>(xp + (3 + j) * PH * 8) = i32x2{l6[2 * j], l6[2 * j + 1]}; \
+            }                                                                                    \
+            unsigned char* const sp = reinterpret_cast<unsigned char*>(smem) + GB_F_BYTES + GB_X_BYTES + wq * 2 * PH + hp; \
+            sp[0] = (unsigned char)eb;                                                           \
+            sp[PH] = (unsigned char)(eb - 11);                                                   \
+        }                                                                                        \
+        tA = nA;                                                                                 \
+        tB = nB;                                                                                 \
+    }
+            f32x16 tA, tB, nA, nB;
+            {   // pair 0's own MFMAs (nothing to hide them behind)
+                float bvA[9], bvB[9];
+                GB_EMB_LOADB(bvA, 0)
+                GB_EMB_LOADB(bvB, 1)
+                tA = ebias;
+                tB = ebias;
 #pragma unroll
-            for (int sT = 0; sT < 9; ++sT) ewt[sT] = p.we[(2 * sT + h) * 128 + 32 * wq + (lane & 31)];
-#pragma unroll
-            for (int t = 0; t < 16; ++t) ebias[t] = p.be[32 * wq + 8 * (t >> 2) + 4 * h + (t & 3)];
-            for (int pair = 0; pair < 6; ++pair) {
-                f32x16 accT[2];
-#pragma unroll
-                for (int tl = 0; tl < 2; ++tl) {
-                    if (pair == 5 && tl == 1) break;                             // pixels 352.. do not exist
-                    int hq = 64 * pair + 32 * tl + (lane & 31);
-                    hq = hq < HP ? hq : HP - 1;
-                    const int hy = (hq * 3641) >> 16;                            // / 18 for 0 <= hq < 324
-                    const int hx = hq - hy * HW;
-                    const float* const pp = patch + ((hy * 20 + hx) * 2 + h);
-#pragma unroll
-                    for (int t = 0; t < 16; ++t) accT[tl][t] = ebias[t];
-#pragma unroll
-                    for (int sT = 0; sT < 9; ++sT)
-                        accT[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(ewt[sT], pp[((sT / 3) * 20 + sT % 3) * 2], accT[tl], 0, 0, 0);
+                for (int sT = 0; sT < 9; ++sT) {
+                    tA = __builtin_amdgcn_mfma_f32_32x32x2f32(ewt[sT], bvA[sT], tA, 0, 0, 0);
+                    tB = __builtin_amdgcn_mfma_f32_32x32x2f32(ewt[sT], bvB[sT], tB, 0, 0, 0);
                 }
-                // lane l < 32: (lo, hi) = tile A's two channel halves of pixel 64 pair + l; l >= 32: tile B's, pixel 64 pair + l
-                float lo[16], hi[16];
-#pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    // (scalar temporaries: __builtin_bit_cast applied to a vector ELEMENT reads element 0, hipcc 7.2)
-                    const float fa_ = accT[0][t], fb_ = accT[1][t];
-                    const unsigned ya = pair == 5 ? 0u : __builtin_bit_cast(unsigned, fb_);
-                    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, fa_), ya, false, false);
-                    const unsigned r0 = r[0], r1 = r[1];
-                    lo[t] = __builtin_bit_cast(float, r0);
-                    hi[t] = __builtin_bit_cast(float, r1);
-                }
-                const int hp = 64 * pair + lane;
-                const bool live = hp < HP;
-                const int hq = live ? hp : HP - 1;
-                const int hy = (hq * 3641) >> 16, hx = hq - hy * HW;
-                const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
-                const bool inside = y >= 0 && y < p.r && x >= 0 && x < p.r;      // outside: the conv's zero padding, not relu(bias)
-                float amax = 0.f;
-#pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    float a = lo[t] > 0.f ? lo[t] : 0.f, b = hi[t] > 0.f ? hi[t] : 0.f;
-                    a = inside ? a : 0.f;
-                    b = inside ? b : 0.f;
-                    a = a > 65504.f ? 65504.f : a;                               // fp16's range (as msr_store_f16c4_dev)
-                    b = b > 65504.f ? 65504.f : b;
-                    lo[t] = a;
-                    hi[t] = b;
-                    amax = fmaxf(amax, fmaxf(a, b));
-                }
-                const int eb = msr_block_e8m0_dev(amax);
-                const float s_hi = __builtin_bit_cast(float, eb << 23);
-                const float s_lo = __builtin_bit_cast(float, (eb - 11) << 23);
-                f32x16 va, vb, la, lb;
-                f16x8 hv[4];
-#pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const _Float16 ha = (_Float16)lo[t], hb = (_Float16)hi[t];
-                    hv[t >> 2][2 * (t & 3)] = ha;                                // position 2t = lo[t], 2t + 1 = hi[t]
-                    hv[t >> 2][2 * (t & 3) + 1] = hb;
-                    va[t] = lo[t];
-                    vb[t] = hi[t];
-                    la[t] = lo[t] - (float)ha;
-                    lb[t] = hi[t] - (float)hb;
-                }
-                // v_cvt_scalef32_2xpk16_fp6_f32 through inline asm with an EARLY-CLOBBER result: the builtin lets hipcc 7.2 put
-                // the 6 result registers on top of the first source (v[34:39] <- v[34:49], ...), and the hardware then reads
-                // clobbered inputs (measured: the h6 piece came out partly wrong, tools/gpu_debug_gbr.py)
-                i32x6 h6, l6;
-                asm volatile("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(h6) : "v"(va), "v"(vb), "v"(s_hi));
-                asm volatile("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(l6) : "v"(la), "v"(lb), "v"(s_lo));
-                if (live) {
-                    char* const fp = smem + (wq * 4 * PH + hp) * 16;
-#pragma unroll
-                    for (int pc = 0; pc < 4; ++pc) *reinterpret_cast<f16x8*>(fp + pc * PH * 16) = hv[pc];
-                    char* const xp = smem + GB_F_BYTES + (wq * 6 * PH + hp) * 8;
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        *reinterpret_cast<i32x2*>(xp + j * PH * 8) = i32x2{h6[2 * j], h6[2 * j + 1]};
-                        *reinterpret_cast<i32x2*>(xp + (3 + j) * PH * 8) = i32x2{l6[2 * j], l6[2 * j + 1]};
-                    }
-                    unsigned char* const sp = reinterpret_cast<unsigned char*>(smem) + GB_F_BYTES + GB_X_BYTES + wq * 2 * PH + hp;
-                    sp[0] = (unsigned char)eb;
-                    sp[PH] = (unsigned char)(eb - 11);
-                }
+                nA = tA;
+                nB = tB;
             }
+            GB_EMB_PAIR(0) GB_EMB_PAIR(1) GB_EMB_PAIR(2) GB_EMB_PAIR(3) GB_EMB_PAIR(4) GB_EMB_PAIR(5)
+            GB_STAMP2()
+#undef GB_EMB_LOADB
+#undef GB_EMB_MFMA
+#undef GB_EMB_PAIR
         }
         __syncthreads();
         GB_STAMP()
@@ -365,22 +411,25 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
             const int n0 = nt * 128;
             const unsigned w_cur = (unsigned)(n0 * CIN) * 4u;
             const unsigned w_nxt = nt + 1 < nt0 + g.nr ? w_cur + 128u * CIN * 4u : w_cur;     // last block: re-reads its own (unused)
+            const int x = tx0 + px;
+            const int ch = ((n0 + (wq >> 1) * 64) >> 1) + (wq & 1) * 16 + 4 * cg;     // first of the lane's 4 output channels
+            const int cb0 = n0 + (wq >> 1) * 64 + (wq & 1) * 16 + 4 * cg;             // its gamma column (beta: + 32)
+            {   // the accumulators start at the conv biases (the lane's 4 gamma and 4 beta columns): nothing to add later
+                const float4 g4 = *reinterpret_cast<const float4*>(p.bias + cb0);
+                const float4 b4 = *reinterpret_cast<const float4*>(p.bias + cb0 + 32);
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+                for (int i = 0; i < 16; ++i) {
+                    acc[i][0] = f32x4{g4.x, g4.y, g4.z, g4.w};
+                    acc[i][1] = f32x4{b4.x, b4.y, b4.z, b4.w};
+                }
+            }
             {
                 const unsigned w_after = w_cur + 2u * BKC * 4u;
                 GB_BODY(0)
             }
-            // the epilogue's memory operands, requested a whole body ahead
-            const int x = tx0 + px;
-            const int ch = ((n0 + (wq >> 1) * 64) >> 1) + (wq & 1) * 16 + 4 * cg;     // first of the lane's 4 output channels
-            const int cb0 = n0 + (wq >> 1) * 64 + (wq & 1) * 16 + 4 * cg;             // its gamma column (beta: + 32)
+            // the epilogue's memory operands are requested ~2 tap pairs ahead (below)
             float4 xin[16];
-            float4 gq4, bq4, mq4, sq4;
+            float4 mq4, sq4;
             {
                 const unsigned w_after = w_nxt;
                 GB_PAIR(2, 0) GB_PAIR(2, 1) GB_PAIR(2, 2) GB_PAIR(2, 3) GB_PAIR(2, 4) GB_PAIR(2, 5) GB_PAIR(2, 6)
@@ -389,51 +438,63 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i)
                         xin[i] = *reinterpret_cast<const float4*>(abase + ((ty0 + i) >> p.aux_shift) * p.aux_py);
-                    gq4 = *reinterpret_cast<const float4*>(p.bias + cb0);
-                    bq4 = *reinterpret_cast<const float4*>(p.bias + cb0 + 32);
                     mq4 = *reinterpret_cast<const float4*>(p.mean + ch);
                     sq4 = *reinterpret_cast<const float4*>(p.stdv + ch);
                 }
                 GB_PAIR(2, 7) GB_PAIR(2, 8)
             }
             // ---- SPADE epilogue: acc[i][0] = gamma, acc[i][1] = beta of channels ch .. ch + 3 at pixel (ty0 + i, x) ----
+            GB_STAMP2()
             {
                 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-                const float gq[4] = {gq4.x, gq4.y, gq4.z, gq4.w}, bq[4] = {bq4.x, bq4.y, bq4.z, bq4.w};
-                const float mq[4] = {mq4.x, mq4.y, mq4.z, mq4.w};
-                const float rs[4] = {1.f / sq4.x, 1.f / sq4.y, 1.f / sq4.z, 1.f / sq4.w};
+                // out = lrelu((acc_g + bias_g) * (x - mean) / std + (acc_b + bias_b)): per channel nk = x * A + Bc
+                const float A[4] = {1.f / sq4.x, 1.f / sq4.y, 1.f / sq4.z, 1.f / sq4.w};
+                const float Bc[4] = {-mq4.x * A[0], -mq4.y * A[1], -mq4.z * A[2], -mq4.w * A[3]};
                 const int half = wq & 1;
                 // the lane's 16 bytes of the pixel's chunk line: fp16 of 8 channels (lane groups 0, 1), h8 / l8 of the 16 (2 / 3)
                 const int doff = cg < 2 ? half * 8 + 4 * cg : (cg == 2 ? 16 + half * 4 : 24 + half * 4);
                 unsigned* const obase = reinterpret_cast<unsigned*>(p.out + (size_t)p.out_off + (size_t)b0 * p.out_pb +
                                                                     x * p.out_px + (ch & ~31)) + doff;
+                // Software pipeline over the 16 tile rows: iteration i requests the assembled line of row i - 1 from LDS, does
+                // the arithmetic of row i beside that read, writes row i's pieces to the other line buffer and stores row i - 1
+                // (LDS operations of one wave execute in order; the round trip per row used to be exposed: 7.6k cycles per block)
+                uint4 q;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    char* const line = stage + (i & 1) * (16 * GB_LINE) + px * GB_LINE;
-                    const float xq[4] = {xin[i].x, xin[i].y, xin[i].z, xin[i].w};
-                    float v[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float normalized = (xq[k] - mq[k]) * rs[k];
-                        const float t = (acc[i][0][k] + gq[k]) * normalized + (acc[i][1][k] + bq[k]);
-                        const float u = t >= 0.f ? t : t * p.slope;
-                        v[k] = u > 65504.f ? 65504.f : (u < -65504.f ? -65504.f : u);
+                for (int i = 0; i <= 16; ++i) {
+                    if (i > 0) {
+                        asm volatile("" ::: "memory");          // the pieces were written through other types
+                        q = *reinterpret_cast<const uint4*>(stage + ((i - 1) & 1) * (16 * GB_LINE) + px * GB_LINE + 16 * cg);
+                        asm volatile("" ::: "memory");
                     }
-                    const h2 a = {(_Float16)v[0], (_Float16)v[1]}, b = {(_Float16)v[2], (_Float16)v[3]};
-                    unsigned h8 = 0, l8 = 0;
-                    h8 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], h8, false);
-                    h8 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], h8, true);
-                    l8 = __builtin_amdgcn_cvt_pk_fp8_f32((v[0] - (float)a[0]) * 2048.f, (v[1] - (float)a[1]) * 2048.f, l8, false);
-                    l8 = __builtin_amdgcn_cvt_pk_fp8_f32((v[2] - (float)b[0]) * 2048.f, (v[3] - (float)b[1]) * 2048.f, l8, true);
-                    *reinterpret_cast<uint2*>(line + 8 * cg) = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
-                    *reinterpret_cast<unsigned*>(line + 32 + 4 * cg) = h8;
-                    *reinterpret_cast<unsigned*>(line + 48 + 4 * cg) = l8;
-                    asm volatile("" ::: "memory");          // the pieces were written through other types
-                    const uint4 q = *reinterpret_cast<const uint4*>(line + 16 * cg);
-                    asm volatile("" ::: "memory");
-                    *reinterpret_cast<uint4*>(obase + (size_t)(ty0 + i) * p.out_py) = q;
+                    if (i < 16) {
+                        char* const line = stage + (i & 1) * (16 * GB_LINE) + px * GB_LINE;
+                        const float xq[4] = {xin[i].x, xin[i].y, xin[i].z, xin[i].w};
+                        float v[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float nk = __builtin_fmaf(xq[k], A[k], Bc[k]);
+                            const float t = __builtin_fmaf(acc[i][0][k], nk, acc[i][1][k]);
+                            const float u = fmaxf(t, t * p.slope);                // leaky relu, 0 <= slope <= 1 (checked on the host)
+                            v[k] = __builtin_amdgcn_fmed3f(u, -65504.f, 65504.f);
+                        }
+                        const h2 a = {(_Float16)v[0], (_Float16)v[1]}, b = {(_Float16)v[2], (_Float16)v[3]};
+                        unsigned h8 = 0;
+                        h8 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], h8, false);
+                        h8 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], h8, true);
+                        // l8 = e4m3((v - hi) * 2^11): the scaled converter divides by its scale operand (2^-11)
+                        typedef short s2_ __attribute__((ext_vector_type(2)));
+                        s2_ l8v = {0, 0};
+                        l8v = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(l8v, v[0] - (float)a[0], v[1] - (float)a[1], 0x1p-11f, false);
+                        l8v = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(l8v, v[2] - (float)b[0], v[3] - (float)b[1], 0x1p-11f, true);
+                        const unsigned l8 = __builtin_bit_cast(unsigned, l8v);
+                        *reinterpret_cast<uint2*>(line + 8 * cg) = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+                        *reinterpret_cast<unsigned*>(line + 32 + 4 * cg) = h8;
+                        *reinterpret_cast<unsigned*>(line + 48 + 4 * cg) = l8;
+                    }
+                    if (i > 0) *reinterpret_cast<uint4*>(obase + (size_t)(ty0 + i - 1) * p.out_py) = q;
                 }
             }
+            GB_STAMP2()
         }
         GB_STAMP()
     }
@@ -442,6 +503,7 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
         for (int k = 0; k + 1 < dbg_n; ++k) printf("gbr wave %d stamp %2d: %7u cycles\n", wq, k, dbg[k + 1] - dbg[k]);
 #endif
 #undef GB_STAMP
+#undef GB_STAMP2
 #undef GB_BUFLD
 #undef GB_CH
 #undef GB_TAP
@@ -482,7 +544,7 @@ int conv_gbr_ranges(int B, int r, int N) {
 hipError_t launch_conv_gbr(const GbrParams& p, int ranges, hipStream_t s) {
     if (ranges < 1 || p.r < 16 || (p.r & (p.r - 1)) || p.N % 128 || (p.N / 128) % ranges || p.out_split != 4 || !p.src || !p.we || !p.be || !p.wt || !p.aux || !p.mean || !p.stdv || !p.out)
         return hipErrorInvalidValue;
-    if (p.f < 1 || p.S != p.r * p.f || p.out_px % 32) return hipErrorInvalidValue;
+    if (p.f < 1 || p.S != p.r * p.f || p.out_px % 32 || !(p.slope >= 0.f && p.slope <= 1.f)) return hipErrorInvalidValue;
     GbrGeom g;
     g.tiles_x = p.r / 16;
     g.tiles_y = p.r / 16;

@@ -19,7 +19,7 @@ for i, f in enumerate(GEN_FILTERS, start=1):
         plan.append((f"rb{i}.gb3", r, 128, 2 * cin)); plan.append((f"rb{i}.conv3", r, cin, f))
     plan.append((f"rb{i}.gb2", r, 128, 2 * f)); plan.append((f"rb{i}.conv2", r, f, f))
     cin = f
-rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"]]   # split-K epilogues excluded
+rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"] or "conv_gb_resident" in r["Kernel_Name"]]   # split-K epilogues excluded
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 n = len(plan)
 calls = len(rows) // n

@@ -54,7 +54,7 @@ def read_pass(path):
     """{dispatch id: (kernel, {counter: value}, start, end)} for the conv_igemm launches."""
     d = {}
     for r in csv.DictReader(open(path)):
-        if "conv_igemm" not in r["Kernel_Name"]:
+        if "conv_igemm" not in r["Kernel_Name"] and "conv_gb_resident" not in r["Kernel_Name"]:
             continue
         k = int(r["Dispatch_Id"])
         e = d.setdefault(k, [r["Kernel_Name"].split("(")[0].replace("void msr::", ""), collections.defaultdict(float),

@@ -108,9 +108,12 @@ def test_graph_replay_equals_eager(Generator):
         xin = x.clone()
         gen.forward_device(xin, out=outs[0])
         gen.forward_device(xin, out=outs[0])         # second sighting: captured
+        st.synchronize()
+        assert torch.equal(outs[0], ref)
         xin.copy_(x_other)                           # same pointer, new content: the graph reads the buffer, not a copy
         gen.forward_device(xin, out=outs[0])
         st.synchronize()
+        assert not torch.equal(outs[0], ref), "the replay did not see the new content of its input buffer (or did not run)"
         assert torch.equal(outs[0], ref_other)
         gen.load(w2)
         y2 = gen.forward_device(x, out=outs[1]).clone()
