@@ -46,10 +46,12 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 
 static constexpr int GB_PH = 336;
 static constexpr int GB_F_BYTES = 16 * GB_PH * 16;
-static constexpr int GB_X_BYTES = 24 * GB_PH * 8;
-static constexpr int GB_SC_BYTES = 8 * GB_PH;
+static constexpr int GB_XA_BYTES = 8 * GB_PH * 16;                   // [chunk][kind][336] x 16 B: bytes 0..15 of a 24-byte fp6 piece
+static constexpr int GB_XB_BYTES = 8 * GB_PH * 8;                    // [chunk][kind][336] x 8 B: bytes 16..23
+static constexpr int GB_X_BYTES = GB_XA_BYTES + GB_XB_BYTES;
+static constexpr int GB_SC_BYTES = 3 * 4 * 2 * 18 * 16;              // [row shift][chunk][kind][halo column] x 16 B (below)
 static constexpr int GB_STAGE_OFF = GB_F_BYTES + GB_X_BYTES + GB_SC_BYTES;
-static constexpr int GB_STAGE_WAVE = 2560;
+static constexpr int GB_STAGE_WAVE = 1504;                           // one 16 x 80-byte line image per wave (>= 1280)
 static constexpr int GB_LINE = 80;                                   // bytes per staged pixel line (64 used)
 #ifdef MSR_GB_STAMPS
 static constexpr size_t GB_LDS = 163840;                             // the stamp words take the last 384 bytes
@@ -98,10 +100,16 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
     // A pair's pieces are the even tap's for lane groups 0, 1 and the odd tap's for 2, 3: the odd tap's halo pixel is 1 (next
     // column), 16 (next row: 18 - 2) or, from tap 8 to tap 0 of the next chunk, one chunk minus 38 pixels further; with that
     // difference in the lane pointer the pair's own position is an immediate offset of the ds_read
-    const char* const XL = smem + GB_F_BYTES + ((cg & 1) * 3 * PH + px) * 8;
-    const char* const XLd[3] = {XL + (cg < 2 ? 0 : 1 * 8), XL + (cg < 2 ? 0 : 16 * 8), XL + (cg < 2 ? 0 : (6 * PH - 38) * 8)};
-    const char* const SL = smem + GB_F_BYTES + GB_X_BYTES + (cg & 1) * PH + px;
-    const char* const SLd[3] = {SL + (cg < 2 ? 0 : 1), SL + (cg < 2 ? 0 : 16), SL + (cg < 2 ? 0 : 2 * PH - 38)};
+    const char* const XA = smem + GB_F_BYTES + ((cg & 1) * PH + px) * 16;
+    const char* const XB = smem + GB_F_BYTES + GB_XA_BYTES + ((cg & 1) * PH + px) * 8;
+    const char* const XAd[3] = {XA + (cg < 2 ? 0 : 1 * 16), XA + (cg < 2 ? 0 : 16 * 16), XA + (cg < 2 ? 0 : (2 * PH - 38) * 16)};
+    const char* const XBd[3] = {XB + (cg < 2 ? 0 : 1 * 8), XB + (cg < 2 ? 0 : 16 * 8), XB + (cg < 2 ? 0 : (2 * PH - 38) * 8)};
+    // block scales: SC[row shift dy][chunk][kind][halo column hx] x 16 bytes, byte i = e8m0 of halo pixel (i + dy, hx): the 16
+    // scales a lane needs for one tap (rows i + dy, column px + dx) are ONE aligned 16-byte read per tap pair, and fragment i
+    // takes byte i & 3 of register i >> 2 through the MFMA's scale byte select
+    const char* const SL = smem + GB_F_BYTES + GB_X_BYTES + ((cg & 1) * 18 + px) * 16;
+    const char* const SLd[3] = {SL + (cg < 2 ? 0 : 16), SL + (cg < 2 ? 0 : (4 * 2 * 18 - 2) * 16),
+                                SL + (cg < 2 ? 0 : (2 * 18 - 2 * 4 * 2 * 18 - 2) * 16)};
     char* const stage = smem + GB_STAGE_OFF + wq * GB_STAGE_WAVE;
     // weight rows of the wave (conv_sw.hip): column block j -> rows 64 * (wq >> 1) + 16 * (wq & 1) + 32 * j + px of the tile
     constexpr int CIN = 128, BKC = 32;
@@ -128,8 +136,9 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
     f32x4 acc[16][2];
     i32x4 bE[2], bO[2], xE[2], xO[2], nbE[2], nbO[2], nxE[2], nxO[2];
     i32x4 fa[16], fb[16];
-    i32x2 xa[16][3];
-    int xs[16];
+    i32x4 xa[16];
+    i32x2 xb[16];
+    i32x4 xsc;                                    // the lane's 16 block scales of the current tap pair
 
 #ifdef MSR_GB_STAMPS
     unsigned* const dbg = reinterpret_cast<unsigned*>(smem + 163840 - 384) + wq * 24;
@@ -278,14 +287,19 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
         if (live) {                                                                              \
             char* const fp = smem + (wq * 4 * PH + hp) * 16;                                     \
             _Pragma("unroll") for (int pc = 0; pc < 4; ++pc) *reinterpret_cast<f16x8*>(fp + pc * PH * 16) = hv[pc]; \
-            char* const xp = smem + GB_F_BYTES + (wq * 6 * PH + hp) * 8;                         \
-            _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                      \
-                *reinterpret_cast<i32x2*>(xp + j * PH * 8) = i32x2{h6[2 * j], h6[2 * j + 1]};    \
-                *reinterpret_cast<i32x2*>(xp + (3 + j) * PH * 8) = i32x2{l6[2 * j], l6[2 * j + 1]}; \
-            }                                                                                    \
-            unsigned char* const sp = reinterpret_cast<unsigned char*>(smem) + GB_F_BYTES + GB_X_BYTES + wq * 2 * PH + hp; \
-            sp[0] = (unsigned char)eb;                                                           \
-            sp[PH] = (unsigned char)(eb - 11);                                                   \
+            char* const xpa = smem + GB_F_BYTES + (wq * 2 * PH + hp) * 16;                       \
+            char* const xpb = smem + GB_F_BYTES + GB_XA_BYTES + (wq * 2 * PH + hp) * 8;          \
+            *reinterpret_cast<i32x4*>(xpa) = i32x4{h6[0], h6[1], h6[2], h6[3]};                  \
+            *reinterpret_cast<i32x4*>(xpa + PH * 16) = i32x4{l6[0], l6[1], l6[2], l6[3]};        \
+            *reinterpret_cast<i32x2*>(xpb) = i32x2{h6[4], h6[5]};                                \
+            *reinterpret_cast<i32x2*>(xpb + PH * 8) = i32x2{l6[4], l6[5]};                       \
+            /* the pixel's scale: byte hy - dy of [dy][chunk][kind][hx] for the row shifts dy with 0 <= hy - dy < 16 */ \
+            unsigned char* const sp = reinterpret_cast<unsigned char*>(smem) + GB_F_BYTES + GB_X_BYTES + (wq * 2 * 18 + hx) * 16 + hy; \
+            _Pragma("unroll") for (int dy = 0; dy < 3; ++dy)                                     \
+                if (hy >= dy && hy - dy < 16) {                                                  \
+                    sp[dy * (4 * 2 * 18 * 16) - dy] = (unsigned char)eb;                         \
+                    sp[dy * (4 * 2 * 18 * 16) - dy + 18 * 16] = (unsigned char)(eb - 11);        \
+                }                                                                                \
         }                                                                                        \
         tA = nA;                                                                                 \
         tB = nB;                                                                                 \
@@ -324,14 +338,14 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
                                           ((GB_CH(CB, T) & 1) * 4 * PH + (i) * HW + GB_TAP(T)) * 16)
         // per-lane pointers of a pair's fp6 pieces and scales: lane groups 0, 1 read the even tap, 2, 3 the odd one
 #define GB_DSEL(TE) ((TE) % 9 == 8 ? 2 : (((TE) % 9) % 3 == 2 ? 1 : 0))
-#define GB_XP(CB, TE) (XLd[GB_DSEL(TE)] + (GB_CH(CB, TE) * 6 * PH + GB_TAP(TE)) * 8)
-#define GB_SP(CB, TE) (SLd[GB_DSEL(TE)] + GB_CH(CB, TE) * 2 * PH + GB_TAP(TE))
-#define GB_RD_X(k, XP, SP, i)                                                                     \
+#define GB_XPA(CB, TE) (XAd[GB_DSEL(TE)] + (GB_CH(CB, TE) * 2 * PH + GB_TAP(TE)) * 16)
+#define GB_XPB(CB, TE) (XBd[GB_DSEL(TE)] + (GB_CH(CB, TE) * 2 * PH + GB_TAP(TE)) * 8)
+    // the 16 scales of the lane's tap: [dy][chunk][kind][px + dx]
+#define GB_SP(CB, TE) (SLd[GB_DSEL(TE)] + (((((TE) % 9) / 3) * 4 + GB_CH(CB, TE)) * 2 * 18 + ((TE) % 9) % 3) * 16)
+#define GB_RD_X(k, XPA, XPB, i)                                                                   \
     {                                                                                            \
-        xa[k][0] = *reinterpret_cast<const i32x2*>((XP) + (i) * HW * 8);                          \
-        xa[k][1] = *reinterpret_cast<const i32x2*>((XP) + (i) * HW * 8 + PH * 8);                 \
-        xa[k][2] = *reinterpret_cast<const i32x2*>((XP) + (i) * HW * 8 + 2 * PH * 8);             \
-        xs[k] = *reinterpret_cast<const unsigned char*>((SP) + (i) * HW);                         \
+        xa[k] = *reinterpret_cast<const i32x4*>((XPA) + (i) * HW * 16);                          \
+        xb[k] = *reinterpret_cast<const i32x2*>((XPB) + (i) * HW * 8);                           \
     }
         // weights of K-step T of the body: byte offset from the channel block's first row
 #define GB_WSOFF(CB, T) ((T) < 18 ? w_cur + (unsigned)(((CB) + (T) / 9) * (BKC * 4)) + (unsigned)((T) % 9) * w_tap_bytes \
@@ -367,11 +381,12 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
 #define GB_PHASE_O(CB, U)                                                                         \
     {                                                                                            \
         constexpr int T = 2 * (U) + 1;                                                           \
-        const char* const xp_ = GB_XP(CB, T - 1);                                                \
-        const char* const sp_ = GB_SP(CB, T - 1);                                                \
+        const char* const xpa_ = GB_XPA(CB, T - 1);                                              \
+        const char* const xpb_ = GB_XPB(CB, T - 1);                                              \
+        xsc = *reinterpret_cast<const i32x4*>(GB_SP(CB, T - 1));                                 \
         _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                         \
             if (i + PD < 16) GB_RD_F(fb[(i + PD) & 15], CB, T, (i + PD) & 15);                   \
-            if (i >= 16 - PDC) GB_RD_X((i + PDC) & 15, xp_, sp_, (i + PDC) & 15)                 \
+            if (i >= 16 - PDC) GB_RD_X((i + PDC) & 15, xpa_, xpb_, (i + PDC) & 15)               \
             acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(GB_F16(bO[0]), GB_F16(fb[i]), acc[i][0], 0, 0, 0); \
             acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(GB_F16(bO[1]), GB_F16(fb[i]), acc[i][1], 0, 0, 0); \
             __builtin_amdgcn_sched_barrier(0);                                                   \
@@ -379,20 +394,26 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
     }
     // Phase C: the cross terms of taps 2U and 2U + 1 (block-scaled K = 128 fp6 MFMA, operands in registers 0..5, the block
     // scales in byte 0 of the scale operands); requests the fp6 pieces ahead, then fa of the next pair's first tap
+#define GB_C_STEP(CB, T, i)                                                                       \
+    {                                                                                            \
+        if ((i) + PDC < 16) GB_RD_X(((i) + PDC) & 15, xpa_, xpb_, ((i) + PDC) & 15)              \
+        if ((i) >= 16 - PD) GB_RD_F(fa[((i) + PD) & 15], CB, (T) + 2, ((i) + PD) & 15);          \
+        const i32x8 aq_ = {xa[i][0], xa[i][1], xa[i][2], xa[i][3], xb[i][0], xb[i][1], 0, 0};    \
+        /* the scale byte select must be a literal: fragment i uses byte i & 3 of scale register i >> 2 */ \
+        acc[i][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wq0_, aq_, acc[i][0], 2, 2, 0, wq0_[6], (i) & 3, xsc[(i) >> 2]); \
+        acc[i][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wq1_, aq_, acc[i][1], 2, 2, 0, wq1_[6], (i) & 3, xsc[(i) >> 2]); \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    }
 #define GB_PHASE_C(CB, U)                                                                         \
     {                                                                                            \
         constexpr int T = 2 * (U);                                                               \
         const i32x8 wq0_ = GB_CAT8(xE[0], xO[0]), wq1_ = GB_CAT8(xE[1], xO[1]);                  \
-        const char* const xp_ = GB_XP(CB, T);                                                    \
-        const char* const sp_ = GB_SP(CB, T);                                                    \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                         \
-            if (i + PDC < 16) GB_RD_X((i + PDC) & 15, xp_, sp_, (i + PDC) & 15)                  \
-            if (i >= 16 - PD) GB_RD_F(fa[(i + PD) & 15], CB, T + 2, (i + PD) & 15);              \
-            const i32x8 aq_ = {xa[i][0][0], xa[i][0][1], xa[i][1][0], xa[i][1][1], xa[i][2][0], xa[i][2][1], 0, 0}; \
-            acc[i][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wq0_, aq_, acc[i][0], 2, 2, 0, wq0_[6], 0, xs[i]); \
-            acc[i][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wq1_, aq_, acc[i][1], 2, 2, 0, wq1_[6], 0, xs[i]); \
-            __builtin_amdgcn_sched_barrier(0);                                                   \
-        }                                                                                        \
+        const char* const xpa_ = GB_XPA(CB, T);                                                  \
+        const char* const xpb_ = GB_XPB(CB, T);                                                  \
+        GB_C_STEP(CB, T, 0) GB_C_STEP(CB, T, 1) GB_C_STEP(CB, T, 2) GB_C_STEP(CB, T, 3)          \
+        GB_C_STEP(CB, T, 4) GB_C_STEP(CB, T, 5) GB_C_STEP(CB, T, 6) GB_C_STEP(CB, T, 7)          \
+        GB_C_STEP(CB, T, 8) GB_C_STEP(CB, T, 9) GB_C_STEP(CB, T, 10) GB_C_STEP(CB, T, 11)        \
+        GB_C_STEP(CB, T, 12) GB_C_STEP(CB, T, 13) GB_C_STEP(CB, T, 14) GB_C_STEP(CB, T, 15)      \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) { bE[j] = nbE[j]; bO[j] = nbO[j]; xE[j] = nxE[j]; xO[j] = nxO[j]; } \
     }
 #define GB_PAIR(CB, U) GB_PHASE_E(CB, U) GB_PHASE_O(CB, U) GB_PHASE_C(CB, U)
@@ -456,18 +477,19 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
                 unsigned* const obase = reinterpret_cast<unsigned*>(p.out + (size_t)p.out_off + (size_t)b0 * p.out_pb +
                                                                     x * p.out_px + (ch & ~31)) + doff;
                 // Software pipeline over the 16 tile rows: iteration i requests the assembled line of row i - 1 from LDS, does
-                // the arithmetic of row i beside that read, writes row i's pieces to the other line buffer and stores row i - 1
+                // the arithmetic of row i beside that read, writes row i's pieces to the line buffer (LDS operations of a wave execute in order: the
+                // read of row i - 1 is ahead of them) and stores row i - 1
                 // (LDS operations of one wave execute in order; the round trip per row used to be exposed: 7.6k cycles per block)
                 uint4 q;
 #pragma unroll
                 for (int i = 0; i <= 16; ++i) {
                     if (i > 0) {
                         asm volatile("" ::: "memory");          // the pieces were written through other types
-                        q = *reinterpret_cast<const uint4*>(stage + ((i - 1) & 1) * (16 * GB_LINE) + px * GB_LINE + 16 * cg);
+                        q = *reinterpret_cast<const uint4*>(stage + px * GB_LINE + 16 * cg);
                         asm volatile("" ::: "memory");
                     }
                     if (i < 16) {
-                        char* const line = stage + (i & 1) * (16 * GB_LINE) + px * GB_LINE;
+                        char* const line = stage + px * GB_LINE;
                         const float xq[4] = {xin[i].x, xin[i].y, xin[i].z, xin[i].w};
                         float v[4];
 #pragma unroll
@@ -508,7 +530,8 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
 #undef GB_CH
 #undef GB_TAP
 #undef GB_RD_F
-#undef GB_XP
+#undef GB_XPA
+#undef GB_XPB
 #undef GB_DSEL
 #undef GB_SP
 #undef GB_RD_X
@@ -519,6 +542,7 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
 #undef GB_PHASE_E
 #undef GB_PHASE_O
 #undef GB_PHASE_C
+#undef GB_C_STEP
 #undef GB_PAIR
 #undef GB_BODY
 }
