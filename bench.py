@@ -11,13 +11,13 @@ over one batch of synthetic (ortho, low-res DEM) patches that is already residen
 Metric: 512x512 DEM tiles/s over the whole job (a 512x512 tile = four 256x256 patches).
 
 Conv arithmetic (--precision; inputs / outputs / weights / accumulation / all other ops fp32 in every mode):
-"f16c" (default) = fp16 main term on v_mfma_f32_16x16x32_f16 + both cross terms on the block-scaled fp8 MFMA in the convs
-that fill the chip (two MFMA-equivalents per product), 3-term split-bf16 elsewhere — 3.6-4.7e-5 relative L-inf vs the
+"f16c" (default) = fp16 main term on v_mfma_f32_16x16x32_f16 + both cross terms on the block-scaled fp8 / fp6 MFMA in the convs
+that fill the chip (2 / 1.5 MFMA-equivalents per product: main convs / SPADE layers), 3-term split-bf16 elsewhere — 3.6-4.7e-5 relative L-inf vs the
 oracle on these very shapes (tests/test_gpu_baseline_configs.py), inside the 1e-3 bar of BASELINE.json; "bf16x3" = 3-term
 split-bf16 everywhere (1.7-2.0e-5); "fp32" = exact fp32 MFMA; "bf16x3_gbf16" opt-in; "fp8" declared non-parity.
 
 At N = 1 the one JSON line also carries, under "also", the driver-timed figures of the other modes and of the other
-single-GPU configuration (spade512 in bf16x3 / bf16x3_gbf16 / fp8, spade256 in f16c / bf16x3 / fp32: value, ms_per_step,
+single-GPU configuration (spade512 in fp32 / bf16x3 / bf16x3_gbf16 / fp8, spade256 in f16c / bf16x3 / fp32: value, ms_per_step,
 roofline each, same K and W), the B = 1 single-call latency ("p50_ms_per_call_b1"), and the CPU baseline.
 
 N > 1: `python bench.py --gpus N` launches its own N workers (fresh child processes of torch.distributed.run, before
@@ -40,7 +40,11 @@ import subprocess
 import sys
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # 2 call streams + 2 auxiliary streams + torch's own: keep them on separate queues
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+# Multi-process GPU work on this pool: the host driver supports only dmabuf IPC, and the pool's environment exports
+# HSA_ENABLE_IPC_MODE_LEGACY=0 for that reason on the build container and on every GPU box (without it RCCL and cross-process
+# tensor sharing fail with "hipIpcGetMemHandle: invalid argument" — the pool operator's environment note, not a measurement of
+# ours).  setdefault only restores that documented default for a caller that scrubbed its environment; an explicit value wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import statistics
 import time
 
@@ -57,10 +61,18 @@ WORKLOADS = {
 # the algorithmic ceiling is a third of the bf16 peak; `achieved` stays ALGORITHMIC FLOP/s in every mode.
 PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16x3_gbf16": 2500.0, "fp8": 5000.0, "f16c": 2500.0}
 # MFMA products per algorithmic product; the opt-in mode runs 2 in the gamma|beta convs (half of the FLOPs), 3 elsewhere
-MFMA_PER_PRODUCT = {"fp32": 1, "bf16x3": 3, "bf16x3_gbf16": 2.5, "fp8": 1, "f16c": 2}
+# f16c since round 3: the gamma|beta convs (half of the FLOPs) run conv_gb_resident with fp6 cross terms (1.5), the main convs 2
+MFMA_PER_PRODUCT = {"fp32": 1, "bf16x3": 3, "bf16x3_gbf16": 2.5, "fp8": 1, "f16c": 1.75}
+# the kernels behind the conv family of each mode (the library's profiler names the family by its base mode)
+KERNELS = {"fp32": "conv_igemm<..., PREC_F32> (v_mfma_f32_32x32x2_f32)",
+           "bf16x3": "conv_igemm_bf16x3_pp (ping-pong, 3-term split-bf16) + small-tile split-K forms",
+           "bf16x3_gbf16": "conv_igemm_bf16x3_pp (gamma|beta convs 2-term fp16, main convs 3-term split-bf16)",
+           "f16c": "conv_gb_resident (SPADE layers: embedding + gamma|beta conv + epilogue, f16 + fp6 cross terms) + "
+                   "conv_igemm_f16c_sw (main convs, f16 + fp8 cross terms); bf16x3 forms on the layers that do not fill the chip",
+           "fp8": "conv_igemm_bf16x3_pp<PP_FP8> (block-scaled v_mfma_scale_f32_16x16x128_f8f6f4, fp8 x fp8); bf16x3 forms elsewhere"}
 DTYPE = {"fp32": "f32", "bf16x3": "bf16x3 (f32 in/out/accumulate)",
          "bf16x3_gbf16": "bf16x3, gamma|beta convs f16x2 (opt-in; f32 in/out/accumulate; 2-5e-4 rel L-inf, inside the 1e-3 bar)",
-         "f16c": "f16 main term + fp8 cross terms in the chip-filling convs, bf16x3 elsewhere (f32 in/out/accumulate; parity mode)",
+         "f16c": "f16 main term + fp8 / fp6 cross terms in the chip-filling convs, bf16x3 elsewhere (f32 in/out/accumulate; parity mode)",
          "fp8": "fp8 e4m3 weights x bf8 e5m2 activations in the chip-filling convs, bf16x3 elsewhere (DECLARED NON-PARITY: "
                 "BASELINE configs[4]; f32 in/out/accumulate; error stated in tests/test_gpu_baseline_configs.py)"}
 
@@ -309,8 +321,10 @@ def run_workload(args, D: Dist, workload: str, precision: str, with_cpu: bool, w
     if conv and conv_union_ms > 0:
         ach = conv["flops"] / (conv_union_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[precision]
-        rl = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-              "traffic": None, "traffic_unit": "bytes per launch (HBM, PMC)", "launches": conv["launches"],
+        rl = {"bound": "mfma", "kernel": KERNELS[precision], "profiler_family": kname, "achieved": ach, "peak": peak,
+              "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+              "traffic_unit": "bytes per launch (memory-side L2 counters of rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE; Infinity-Cache "
+                              "hits are counted as traffic by these counters)", "launches": conv["launches"],
               "avg_launch_ms": conv_union_ms / conv["launches"], "family_busy_ms": conv_union_ms,
               "sum_of_intervals_ms": conv["device_ms"],
               "algorithmic_flops_per_launch": conv["flops"] / conv["launches"]}
@@ -318,9 +332,9 @@ def run_workload(args, D: Dist, workload: str, precision: str, with_cpu: bool, w
             k = MFMA_PER_PRODUCT[precision]
             rl["mfma_executed_tflops"] = k * ach
             rl["frac_of_executed_mfma_peak"] = k * ach / peak
-            rl["note"] = (f"frac = algorithmic FLOP/s over the dense bf16/f16 MFMA peak; {precision} issues {k} MFMA "
-                          "products per algorithmic product (average over the conv FLOPs), so the matrix pipe executes "
-                          "that multiple of `achieved` (frac_of_executed_mfma_peak) and frac is capped at 1/" + str(k))
+            rl["note"] = (f"frac = algorithmic FLOP/s over the dense bf16/f16 MFMA peak; {precision} issues {k} MFMA-"
+                          "equivalents per algorithmic product (average over the conv FLOPs), so the matrix pipe executes "
+                          f"that multiple of `achieved` (frac_of_executed_mfma_peak) and frac is capped at {1 / k:.3f}")
         # the modes that keep the split-bf16 tensor geometry move the same bytes: fall back to the bf16x3 passes
         pmc = pmc_traffic(workload + ("" if precision == "fp32" else "_" + precision)) or (
             pmc_traffic(workload + "_bf16x3") if precision in ("f16c", "bf16x3_gbf16") else None)
@@ -404,8 +418,8 @@ def main():
                        with_b1=solo and not args.no_also)
     if solo and not args.no_also:
         also = {}
-        for wl, prec in (("spade512", "bf16x3"), ("spade512", "bf16x3_gbf16"), ("spade512", "fp8"), ("spade256", "f16c"),
-                         ("spade256", "bf16x3"), ("spade256", "fp32")):
+        for wl, prec in (("spade512", "fp32"), ("spade512", "bf16x3"), ("spade512", "bf16x3_gbf16"), ("spade512", "fp8"),
+                         ("spade256", "f16c"), ("spade256", "bf16x3"), ("spade256", "fp32")):
             if (wl, prec) == (args.workload, args.precision):
                 continue
             r = run_workload(args, D, wl, prec, with_cpu=False, with_b1=False)

@@ -266,8 +266,9 @@ int msr_op_conv3x3_f16c(msr_handle* h, const float* in_dev, const float* wt_dev,
  *   GEMM with N = 2C columns interleaved (32 gamma | 32 beta), gamma * (x - mean) / std + beta (spade.py:21-24), leaky_relu(0.2)
  *   (blocks.py:30-34), written as the f16c chunk image of the consumer conv.
  *   src_dev  [B, S, S, 2] fp32 (S = r * 2^k); we_dev HWIO [3,3,2,128]; be_dev [128]
- *   wt_dev   f16c6 image (ops.f16c6_weight_image) of [9][N][128] with the input channels of every 32-chunk in the kernel's
- *            position order: position e holds channel 8 * (e >> 3) + 4 * (e & 1) + ((e >> 1) & 3)
+ *   wt_dev   the kernel's weight stream (ops.gbr_weight_image restates it): the f16c6 image of [9][N][128] with the input
+ *            channels of every 32-chunk in position order (position e holds channel 8 * (e >> 3) + 4 * (e & 1) + ((e >> 1) & 3)),
+ *            re-ordered into [channel block][wave][tap pair][column block][piece][lane] x 16 bytes (csrc/conv_gbr.hip)
  *   bias_dev [N] in column order; aux_dev = x [B, r >> aux_shift, r >> aux_shift, N / 2]; mean_dev / std_dev [N / 2]
  *   out_dev  zero-bordered [B, r + 2, r + 2, N / 2] float slots, the interior is written
  * Needs r >= 32 (a power of two) and N % 128 == 0; MSR_ERR_INVALID otherwise. */

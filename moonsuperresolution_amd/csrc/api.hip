@@ -357,8 +357,7 @@ bool main_uses_f16c6(msr_handle* h, int rout, int cin, int cout) {
 
 // f16c6 image of [taps][N][Cin] weights (kernels.h PREC_F16C6): per 32-channel chunk [32 x hi f16 | 24 B l6 | e8m0 | 0.. |
 // 24 B h6 | e8m0 | 0..], one power-of-two scale per output channel and piece (2^E >= max / 7.5)
-int upload_conv_weight_f16c6(msr_handle* h, const std::string& key, const float* host, int taps, int N, int Cin) {
-    if (Cin % 32) return fail(h, MSR_ERR_INVALID, "%s: f16c6 needs Cin %% 32 == 0", key.c_str());
+std::vector<float> build_f16c6_image(const float* host, int taps, int N, int Cin) {
     std::vector<float> img((size_t)taps * N * Cin, 0.f);
     auto pow2exp = [](float amax) {
         if (!(amax > 0.f)) return 0;
@@ -398,7 +397,44 @@ int upload_conv_weight_f16c6(msr_handle* h, const std::string& key, const float*
                 chunk[120] = (unsigned char)(127 + eh);
             }
     }
+    return img;
+}
+int upload_conv_weight_f16c6(msr_handle* h, const std::string& key, const float* host, int taps, int N, int Cin) {
+    if (Cin % 32) return fail(h, MSR_ERR_INVALID, "%s: f16c6 needs Cin %% 32 == 0", key.c_str());
+    const std::vector<float> img = build_f16c6_image(host, taps, N, Cin);
     return upload(h, key, img.data(), img.size());
+}
+
+// The weight stream of conv_gb_resident (conv_gbr.hip): the f16c6 image of [9][N][128] (input channels of every 32-chunk in
+// the kernel's position order, gbr_perm) re-ordered into the order the kernel's waves load it — for channel block nt, wave q,
+// tap pair P (K-steps 2P, 2P + 1 of the 36-step chunk-major sequence: step T = chunk T / 9, tap T % 9), column block j, piece
+// (0 / 1: fp16 fragment of the even / odd step, 2 / 3: first / second 16 bytes of the lane's fp6 piece), lane: 16 bytes.
+// Lane (px, cg): row = 128 nt + 64 (q >> 1) + 16 (q & 1) + 32 j + px; fp16 fragment = bytes 16 cg .. of the record; fp6 piece =
+// bytes 64 + 32 (cg & 1) .. of the even step's record (cg < 2) or the odd step's (cg >= 2).
+std::vector<float> gbr_weight_stream(const float* w_tap_n_k, int N) {
+    const int Cin = 128;
+    std::vector<float> perm((size_t)9 * N * Cin);
+    for (size_t row = 0; row < (size_t)9 * N; ++row)
+        for (int k = 0; k < Cin; ++k) perm[row * Cin + k] = w_tap_n_k[row * Cin + (k & ~31) + gbr_perm(k & 31)];
+    const std::vector<float> img = build_f16c6_image(perm.data(), 9, N, Cin);
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(img.data());
+    std::vector<float> out(img.size());
+    unsigned char* dst = reinterpret_cast<unsigned char*>(out.data());
+    auto rec = [&](int T, int row) { return src + (((size_t)(T % 9) * N + row) * 4 + T / 9) * 128; };
+    for (int nt = 0; nt < N / 128; ++nt)
+        for (int q = 0; q < 4; ++q)
+            for (int P = 0; P < 18; ++P)
+                for (int j = 0; j < 2; ++j)
+                    for (int piece = 0; piece < 4; ++piece)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int px = lane & 15, cg = lane >> 4;
+                            const int row = 128 * nt + 64 * (q >> 1) + 16 * (q & 1) + 32 * j + px;
+                            const unsigned char* s;
+                            if (piece < 2) s = rec(2 * P + piece, row) + 16 * cg;
+                            else s = rec(2 * P + (cg >> 1), row) + 64 + 32 * (cg & 1) + 16 * (piece - 2);
+                            std::memcpy(dst + ((((((size_t)nt * 4 + q) * 18 + P) * 2 + j) * 4 + piece) * 64 + lane) * 16, s, 16);
+                        }
+    return out;
 }
 
 // f16c image of [taps][N][Cin] weights (kernels.h PREC_F16C): per 32-channel chunk [32 x hi f16 | 32 x l8 | 32 x h8]
@@ -747,10 +783,8 @@ int msr_load_weight(msr_handle* h, const char* name_c, const float* host, const 
             const int cout_main = blk >= 1 && blk <= 6 ? kGenFilters[blk - 1] : 0;     // every conv of block i has kGenFilters[i-1] outputs
             if (gb_uses_fp8(h, rout, C)) rc = upload_conv_weight_fp8(h, base + ".gb.kernel", img.data(), 9, 2 * C, cin);
             else if (cin == 128 && cout_main && gb_uses_gbr(h, rout, C, cout_main)) {
-                std::vector<float> perm(img.size());
-                for (size_t row = 0; row < (size_t)9 * 2 * C; ++row)
-                    for (int k = 0; k < cin; ++k) perm[row * cin + k] = img[row * cin + (k & ~31) + gbr_perm(k & 31)];
-                rc = upload_conv_weight_f16c6(h, base + ".gb.kernel", perm.data(), 9, 2 * C, cin);
+                const std::vector<float> ws = gbr_weight_stream(img.data(), 2 * C);
+                rc = upload(h, base + ".gb.kernel", ws.data(), ws.size());
             }
             else if (gb_uses_f16c(h, rout, C)) rc = upload_conv_weight_f16c(h, base + ".gb.kernel", img.data(), 9, 2 * C, cin);
             else

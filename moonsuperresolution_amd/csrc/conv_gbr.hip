@@ -111,26 +111,16 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
     const char* const SLd[3] = {SL + (cg < 2 ? 0 : 16), SL + (cg < 2 ? 0 : (4 * 2 * 18 - 2) * 16),
                                 SL + (cg < 2 ? 0 : (2 * 18 - 2 * 4 * 2 * 18 - 2) * 16)};
     char* const stage = smem + GB_STAGE_OFF + wq * GB_STAGE_WAVE;
-    // weight rows of the wave (conv_sw.hip): column block j -> rows 64 * (wq >> 1) + 16 * (wq & 1) + 32 * j + px of the tile
-    constexpr int CIN = 128, BKC = 32;
-    int b_voff[2], b_xoff[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row_ = (((wq >> 1) * 64 + (wq & 1) * 16 + 32 * j + px) * CIN) * 4;
-        b_voff[j] = row_ + 16 * cg;
-        b_xoff[j] = row_ + 64 + 32 * (cg & 1);                                   // l6 piece (even groups) | h6 piece (odd)
-    }
-    const unsigned w_tap_bytes = (unsigned)((size_t)p.N * CIN * sizeof(float));
-    // lane offset of the fp6 piece incl. the distance of the lane's tap from the pair's smaller weight offset: the odd tap is
-    // one tap further (normal pair), or the EVEN tap is 8 taps minus one chunk further (tap 8 | tap 0 of the next chunk)
-    int b_xoffn[2], b_xoffw[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        b_xoffn[j] = b_xoff[j] + (cg < 2 ? 0 : (int)w_tap_bytes);
-        b_xoffw[j] = b_xoff[j] + (cg < 2 ? (int)(8u * w_tap_bytes) - BKC * 4 : 0);
-    }
-    const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.wt), 0, (int)(9u * w_tap_bytes), 0x00020000);
+    // Weight stream (GbrParams.wt, built by the host: api.hip gbr_weight_stream / ops.gbr_weight_image): for channel block nt,
+    // wave q and tap pair P (K-steps 2P, 2P + 1 of the 36-step chunk-major sequence) 8 KB = [column block j][piece][lane] x 16 B
+    // with piece 0 / 1 = the fp16 fragments of the even / odd tap, 2 / 3 = the two halves of the lane's fp6 piece: every load
+    // instruction reads 1 KB of consecutive bytes (8 whole cache lines; the [tap][row][chunk] image made the fp6 loads touch
+    // 32 lines each: texture addresser 75 % busy, 40 % address-stalled, profiles/r03_conv_colimiters_f16c_gbr_v1.txt).
+    // Column block j of wave q = rows 64 * (q >> 1) + 16 * (q & 1) + 32 * j + px of the channel block (conv_sw.hip's map).
+    constexpr int CIN = 128;
+    const int wv[2] = {lane * 16, lane * 16 + 4096};
+    const unsigned w_stream_bytes = (unsigned)((size_t)9 * p.N * CIN * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, (int)w_stream_bytes, 0x00020000);
 #define GB_BUFLD(voff, soff) __builtin_amdgcn_raw_buffer_load_b128(rs_wt, voff, (int)(soff), 0)
 
     f32x4 acc[16][2];
@@ -347,19 +337,14 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
         xa[k] = *reinterpret_cast<const i32x4*>((XPA) + (i) * HW * 16);                          \
         xb[k] = *reinterpret_cast<const i32x2*>((XPB) + (i) * HW * 8);                           \
     }
-        // weights of K-step T of the body: byte offset from the channel block's first row
-#define GB_WSOFF(CB, T) ((T) < 18 ? w_cur + (unsigned)(((CB) + (T) / 9) * (BKC * 4)) + (unsigned)((T) % 9) * w_tap_bytes \
-                                  : w_after + (unsigned)((T) - 18) * w_tap_bytes)
-#define GB_LOAD_B(dstE, dstO, dxE, dxO, CB, T, j)                                                 \
+        // weights of tap pair P of the channel block (P = 18: pair 0 of the next block, or of this one again on the last)
+#define GB_WSOFF(P) ((P) < 18 ? w_cur + (unsigned)(P) * 8192u : w_nxt)
+#define GB_LOAD_B(dstE, dstO, dxE, dxO, P, j)                                                     \
     {                                                                                            \
-        dstE[j] = GB_BUFLD(b_voff[j], GB_WSOFF(CB, T));                                          \
-        dstO[j] = GB_BUFLD(b_voff[j], GB_WSOFF(CB, (T) + 1));                                    \
-        /* both 16-byte halves of the lane's fp6 piece, from the even tap's row (lane groups 0, 1) or the odd tap's (2, 3);  \
-           the scalar offset is the smaller of the two taps' (the other one's excess rides in the lane offset) */ \
-        const unsigned lo_ = (T) % 9 == 8 && (T) < 18 ? GB_WSOFF(CB, (T) + 1) : GB_WSOFF(CB, T); \
-        const int xo_ = (T) % 9 == 8 && (T) < 18 ? b_xoffw[j] : b_xoffn[j];                      \
-        dxE[j] = GB_BUFLD(xo_, lo_);                                                             \
-        dxO[j] = GB_BUFLD(xo_ + 16, lo_);                                                        \
+        dstE[j] = GB_BUFLD(wv[j], GB_WSOFF(P));                                                  \
+        dstO[j] = GB_BUFLD(wv[j] + 1024, GB_WSOFF(P));                                           \
+        dxE[j] = GB_BUFLD(wv[j] + 2048, GB_WSOFF(P));                                            \
+        dxO[j] = GB_BUFLD(wv[j] + 3072, GB_WSOFF(P));                                            \
     }
 #define GB_F16(v) __builtin_bit_cast(f16x8, v)
 #define GB_CAT8(lo, hi) __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)
@@ -370,8 +355,8 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
         _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                         \
             if (i + PD < 16) GB_RD_F(fa[(i + PD) & 15], CB, T, (i + PD) & 15);                   \
             else GB_RD_F(fb[(i + PD) & 15], CB, T + 1, (i + PD) & 15);                           \
-            if (i == 0) GB_LOAD_B(nbE, nbO, nxE, nxO, CB, T + 2, 0)                              \
-            if (i == 8) GB_LOAD_B(nbE, nbO, nxE, nxO, CB, T + 2, 1)                              \
+            if (i == 0) GB_LOAD_B(nbE, nbO, nxE, nxO, ((CB) / 2) * 9 + (U) + 1, 0)               \
+            if (i == 8) GB_LOAD_B(nbE, nbO, nxE, nxO, ((CB) / 2) * 9 + (U) + 1, 1)               \
             acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(GB_F16(bE[0]), GB_F16(fa[i]), acc[i][0], 0, 0, 0); \
             acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(GB_F16(bE[1]), GB_F16(fa[i]), acc[i][1], 0, 0, 0); \
             __builtin_amdgcn_sched_barrier(0);                                                   \
@@ -421,17 +406,17 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
 
         // prologue of the sweep: the weights of taps 0 and 1 of the first channel block, the first PD pixel fragments
         {
-            const unsigned w_cur = (unsigned)(nt0 * 128 * CIN) * 4u, w_after = w_cur;
-            GB_LOAD_B(bE, bO, xE, xO, 0, 0, 0)
-            GB_LOAD_B(bE, bO, xE, xO, 0, 0, 1)
+            const unsigned w_cur = (unsigned)((nt0 * 4 + wq) * 18) * 8192u, w_nxt = w_cur;
+            GB_LOAD_B(bE, bO, xE, xO, 0, 0)
+            GB_LOAD_B(bE, bO, xE, xO, 0, 1)
         }
 #pragma unroll
         for (int i = 0; i < PD; ++i) GB_RD_F(fa[i], 0, 0, i);
 
         for (int nt = nt0; nt < nt0 + g.nr; ++nt) {
             const int n0 = nt * 128;
-            const unsigned w_cur = (unsigned)(n0 * CIN) * 4u;
-            const unsigned w_nxt = nt + 1 < nt0 + g.nr ? w_cur + 128u * CIN * 4u : w_cur;     // last block: re-reads its own (unused)
+            const unsigned w_cur = (unsigned)((nt * 4 + wq) * 18) * 8192u;
+            const unsigned w_nxt = nt + 1 < nt0 + g.nr ? w_cur + 4u * 18u * 8192u : w_cur;    // last block: re-reads its own (unused)
             const int x = tx0 + px;
             const int ch = ((n0 + (wq >> 1) * 64) >> 1) + (wq & 1) * 16 + 4 * cg;     // first of the lane's 4 output channels
             const int cb0 = n0 + (wq >> 1) * 64 + (wq & 1) * 16 + 4 * cg;             // its gamma column (beta: + 32)
@@ -444,15 +429,11 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
                     acc[i][1] = f32x4{b4.x, b4.y, b4.z, b4.w};
                 }
             }
-            {
-                const unsigned w_after = w_cur + 2u * BKC * 4u;
-                GB_BODY(0)
-            }
+            GB_BODY(0)
             // the epilogue's memory operands are requested ~2 tap pairs ahead (below)
             float4 xin[16];
             float4 mq4, sq4;
             {
-                const unsigned w_after = w_nxt;
                 GB_PAIR(2, 0) GB_PAIR(2, 1) GB_PAIR(2, 2) GB_PAIR(2, 3) GB_PAIR(2, 4) GB_PAIR(2, 5) GB_PAIR(2, 6)
                 {   // ~2 tap pairs (4000 cycles) before their use
                     const float* const abase = p.aux + (size_t)b0 * p.aux_pb + (x >> p.aux_shift) * p.aux_px + ch;

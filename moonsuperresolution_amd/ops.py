@@ -343,10 +343,25 @@ GBR_PERM = [8 * (e >> 3) + 4 * (e & 1) + ((e >> 1) & 3) for e in range(32)]   # 
 
 
 def gbr_weight_image(w_kl: torch.Tensor) -> torch.Tensor:
-    """gamma|beta weights [9][N][128] (kernel layout, spade_layout rows) -> the image conv_gb_resident reads: the f16c6 image
-    with the input channels of every 32-chunk in the kernel's position order."""
+    """gamma|beta weights [9][N][128] (kernel layout, spade_layout rows) -> the weight STREAM conv_gb_resident reads: the f16c6
+    image with the input channels of every 32-chunk in the kernel's position order, re-ordered into the order its waves load
+    it: [channel block nt][wave q][tap pair P][column block j][piece][lane] x 16 bytes (csrc/conv_gbr.hip, api.hip
+    gbr_weight_stream).  Returned as float32 storage [9][N][128] (same byte count)."""
+    N = w_kl.shape[1]
     idx = torch.tensor([32 * c + GBR_PERM[e] for c in range(w_kl.shape[2] // 32) for e in range(32)], device=w_kl.device)
-    return f16c6_weight_image(w_kl[:, :, idx].contiguous())[0]
+    img = f16c6_weight_image(w_kl[:, :, idx].contiguous())[0]
+    rec = img.contiguous().view(torch.uint8).reshape(9, N, 4, 128)                 # [tap][row][chunk][128 bytes]
+    dev = w_kl.device
+    nt, q, P, j, piece, lane = torch.meshgrid(torch.arange(N // 128), torch.arange(4), torch.arange(18), torch.arange(2),
+                                              torch.arange(4), torch.arange(64), indexing="ij")
+    px, cg = lane & 15, lane >> 4
+    row = 128 * nt + 64 * (q >> 1) + 16 * (q & 1) + 32 * j + px
+    T = torch.where(piece < 2, 2 * P + piece, 2 * P + (cg >> 1))
+    off = torch.where(piece < 2, 16 * cg, 64 + 32 * (cg & 1) + 16 * (piece - 2))
+    tap, chunk = (T % 9).to(dev), (T // 9).to(dev)
+    byte = off.to(dev)[..., None] + torch.arange(16, device=dev)
+    out = rec[tap[..., None], row.to(dev)[..., None], chunk[..., None], byte]        # [..., 16] bytes
+    return out.contiguous().reshape(-1).view(torch.float32).reshape(9, N, 128)
 
 
 def spade_gbr(ctx: OpContext, src: torch.Tensor, we: torch.Tensor, be: torch.Tensor, w_img: torch.Tensor, bias: torch.Tensor,

@@ -21,7 +21,7 @@ import sys
 import time
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # the tile loop alternates two generator handles (4 streams in all)
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the pool's documented environment (dmabuf IPC only): see bench.py
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -70,6 +70,8 @@ def main():
                     help="patch-row-sharded mode (halo.py): every patch position generated once, neighbour exchange of "
                          "the boundary-zone accumulators over send / recv; NOT reference-identical (see halo.py)")
     ap.add_argument("--passes", type=int, default=1, help="run the shard this many times; the last pass is reported")
+    ap.add_argument("--dump", default="", help="rank 0 writes the finished products (mean, std, good) to this .npz: the gathered "
+                                               "rows with --gather, else its own rows (tests compare them across process counts)")
     ap.add_argument("--precision", default="f16c")
     ap.add_argument("--pipeline", type=int, default=2)
     args = ap.parse_args()
@@ -152,6 +154,8 @@ def main():
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        if args.dump and rank == 0:
+            np.savez(args.dump, mean=m.cpu().numpy(), std=sd.cpu().numpy(), good=g.cpu().numpy(), own=np.array([own_lo, own_hi]))
         nv, nc = hs.last_counts_halo
         tot = torch.tensor([nv, nc], dtype=torch.float64, device="cuda")
         mx = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -211,6 +215,8 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if args.dump and rank == 0:
+        np.savez(args.dump, mean=prod[0].cpu().numpy(), std=prod[1].cpu().numpy(), good=prod[2].cpu().numpy())
     good_fraction = float(prod[2][:, :args.cols].float().mean()) if prod[2].numel() else 0.0
     # generator-only references on rank 0's device: the same number of calls over the same handles / streams, no tiler
     # and no stitcher — (a) on the patches the tile loop left in its batch buffers (real data: clocks under load depend

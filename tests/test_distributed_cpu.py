@@ -16,18 +16,54 @@ def _fake_tile(xx, yy, T=64):
             (rng.uniform(0, 1, (T, T)) > 0.2).astype(np.uint8))
 
 
-def _worker(rank, world, port, shape, T, q):
+def _smooth_model(x, training=False):
+    """A non-trivial stand-in generator (mixes the two channels and neighbouring pixels): the stitched result depends on
+    every patch and on its position, unlike the identity model."""
+    x = np.asarray(x, np.float32)
+    y = 0.6 * x[..., 1:2] + 0.4 * x[..., 0:1]
+    y[:, 1:, 1:] += 0.05 * y[:, :-1, :-1]
+    return y
+
+
+def _oracle_tile_fn(shape, S, s, B, T):
+    """process_tile(xx, yy) of the ORACLE's real tile path (pad -> patches -> validity -> normalise -> batches ->
+    model -> rebuildTile, oracle/tiler_ref.py::process_tile = process_full_tiles.py:431-479) on a synthetic raster."""
+    from oracle import tiler_ref
+    from tests.helpers import synthetic_raster
+    img, dem = synthetic_raster(shape[0], shape[1], seed=11, hole=(30, 70, 40, 90))
+    img_p, dem_p = tiler_ref.pad_inputs(img, dem, S, s, -32768.0)
+    return lambda xx, yy: tiler_ref.process_tile(img_p, dem_p, xx, yy, _smooth_model, S, s, B, T, -32768.0)
+
+
+def _worker(rank, world, port, shape, T, q, real):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     tiles = [(xx, yy) for yy in range(0, shape[0], T) for xx in range(0, shape[1], T)]
-    out = process_map_sharded(shape, T, tiles, lambda x, y: _fake_tile(x, y, T), rank, world, gather=True)
+    fn = _oracle_tile_fn(shape, 32, 8, 5, T) if real else (lambda x, y: _fake_tile(x, y, T))
+    out = process_map_sharded(shape, T, tiles, fn, rank, world, gather=True)
     q.put((rank, [o.copy() for o in out]))
     dist.barrier()
     dist.destroy_process_group()
 
 
 import pytest
+
+
+def _run_world(world, shape, T, real):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, T, q, real)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return results
 
 
 @pytest.mark.parametrize("world,shape", [
@@ -39,21 +75,27 @@ def test_sharded_map_equals_single_process(world, shape):
     T = 64
     tiles = [(xx, yy) for yy in range(0, shape[0], T) for xx in range(0, shape[1], T)]
     single = process_map_sharded(shape, T, tiles, lambda x, y: _fake_tile(x, y, T), 0, 1)
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, T, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    results = dict(q.get(timeout=120) for _ in range(world))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    results = _run_world(world, shape, T, real=False)
     for r in range(world):
         for a, b in zip(results[r], single):
             assert a.shape == shape and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("world,shape", [(2, (200, 150)), (3, (250, 100))])
+def test_sharded_real_tile_path_equals_the_oracle_map(world, shape):
+    """The REAL tile function in separate processes: every rank runs the oracle's process_tile (patch cutting, validity,
+    normalisation, zero-padded last batch, stitcher) on its tile rows; the gathered map equals oracle process_map of the
+    whole raster bit for bit (process_full_tiles.py:313-325,431-479 sharded by tile row)."""
+    from oracle import tiler_ref
+    from tests.helpers import synthetic_raster
+    T, S, s, B = 64, 32, 8, 5
+    img, dem = synthetic_raster(shape[0], shape[1], seed=11, hole=(30, 70, 40, 90))
+    want = tiler_ref.process_map(img, dem, _smooth_model, S, s, B, T, -32768.0)
+    results = _run_world(world, shape, T, real=True)
+    for r in range(world):
+        for a, b in zip(results[r], want):
+            assert a.shape == shape and np.array_equal(a, b, equal_nan=True)
+    assert want[2].any() and not want[2].all()
 
 
 def test_uneven_rows_three_ranks_layout():
