@@ -133,11 +133,13 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
 #ifdef MSR_GB_STAMPS
     unsigned* const dbg = reinterpret_cast<unsigned*>(smem + 163840 - 384) + wq * 24;
     int dbg_n = 0;
-#define GB_STAMP() if (blockIdx.x == 8 && lane == 0 && dbg_n < 24) dbg[dbg_n++] = (unsigned)__builtin_amdgcn_s_memtime();
-#define GB_STAMP2() if (MSR_GB_STAMPS >= 2) GB_STAMP()
+#define GB_STAMP() { if (blockIdx.x == 8 && lane == 0 && dbg_n < 24) dbg[dbg_n++] = (unsigned)__builtin_amdgcn_s_memtime(); }
+#define GB_STAMP2() { if (MSR_GB_STAMPS == 2) GB_STAMP() }
+#define GB_STAMP3() { if (MSR_GB_STAMPS == 3) GB_STAMP() }
 #else
-#define GB_STAMP()
-#define GB_STAMP2()
+#define GB_STAMP() {}
+#define GB_STAMP2() {}
+#define GB_STAMP3() {}
 #endif
 
     for (int it = blockIdx.x >> 3; it < cnt; it += slots) {
@@ -229,6 +231,7 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
         if (nextA) GB_EMB_LOADB(bvA, 2 * ((PAIR) + 1))                                            \
         if (nextB) GB_EMB_LOADB(bvB, 2 * ((PAIR) + 1) + 1)                                        \
         __builtin_amdgcn_sched_barrier(0);                                                       \
+        if ((PAIR) == 1) GB_STAMP3()                                                             \
         const int hp = 64 * (PAIR) + lane1;                                                       \
         const bool live = hp < HP;                                                               \
         const int hq = live ? hp : HP - 1;                                                       \
@@ -239,18 +242,31 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
         const float top = (y >= 0 && y < p.r && x >= 0 && x < p.r) ? 65504.f : 0.f;              \
         float lo[16], hi[16];                                                                    \
         float amax = 0.f;                                                                        \
+        /* the pair's 32 results leave the accumulator registers BEFORE the next pair's MFMAs are issued: a             \
+           v_accvgpr_read beside an MFMA in flight waits for it (measured: MFMAs and conversion ran one after the other) */ \
         _Pragma("unroll") for (int t = 0; t < 16; ++t) {                                         \
             /* (scalar temporaries: __builtin_bit_cast applied to a vector ELEMENT reads element 0, hipcc 7.2) */ \
             const float fa_ = tA[t], fb_ = tB[t];                                                \
             const unsigned ya_ = (PAIR) == 5 ? 0u : __builtin_bit_cast(unsigned, fb_);           \
             const auto r_ = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, fa_), ya_, false, false); \
             const unsigned r0_ = r_[0], r1_ = r_[1];                                             \
-            lo[t] = __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, r0_), 0.f, top);           \
-            hi[t] = __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, r1_), 0.f, top);           \
+            lo[t] = __builtin_bit_cast(float, r0_);                                              \
+            hi[t] = __builtin_bit_cast(float, r1_);                                              \
+        }                                                                                        \
+        asm volatile("" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]),   \
+                          "+v"(lo[8]), "+v"(lo[9]), "+v"(lo[10]), "+v"(lo[11]), "+v"(lo[12]), "+v"(lo[13]), "+v"(lo[14]), "+v"(lo[15])); \
+        asm volatile("" : "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]), "+v"(hi[5]), "+v"(hi[6]), "+v"(hi[7]),   \
+                          "+v"(hi[8]), "+v"(hi[9]), "+v"(hi[10]), "+v"(hi[11]), "+v"(hi[12]), "+v"(hi[13]), "+v"(hi[14]), "+v"(hi[15])); \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if ((PAIR) == 1) GB_STAMP3()                                                             \
+        _Pragma("unroll") for (int t = 0; t < 16; ++t) {                                         \
+            lo[t] = __builtin_amdgcn_fmed3f(lo[t], 0.f, top);                                    \
+            hi[t] = __builtin_amdgcn_fmed3f(hi[t], 0.f, top);                                    \
             amax = fmaxf(amax, fmaxf(lo[t], hi[t]));                                             \
             if (t < 10) GB_EMB_MFMA(t)                                                           \
             __builtin_amdgcn_sched_barrier(0);                                                   \
         }                                                                                        \
+        if ((PAIR) == 1) GB_STAMP3()                                                             \
         const int eb = msr_block_e8m0_dev(amax);                                                 \
         const float s_hi = __builtin_bit_cast(float, eb << 23);                                  \
         const float s_lo = __builtin_bit_cast(float, (eb - 11) << 23);                           \
@@ -271,6 +287,7 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
         /* v_cvt_scalef32_2xpk16_fp6_f32 through inline asm with an EARLY-CLOBBER result: the builtin lets hipcc 7.2 put \
            the 6 result registers on top of the first source (v[34:39] <- v[34:49], ...), and the hardware then reads    \
            clobbered inputs (measured: the h6 piece came out partly wrong, tools/gpu_debug_gbr.py) */ \
+        if ((PAIR) == 1) GB_STAMP3()                                                             \
         i32x6 h6, l6;                                                                            \
         asm volatile("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(h6) : "v"(va), "v"(vb), "v"(s_hi)); \
         asm volatile("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(l6) : "v"(la), "v"(lb), "v"(s_lo)); \
@@ -291,6 +308,7 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
                     sp[dy * (4 * 2 * 18 * 16) - dy + 18 * 16] = (unsigned char)(eb - 11);        \
                 }                                                                                \
         }                                                                                        \
+        if ((PAIR) == 1) GB_STAMP3()                                                             \
         tA = nA;                                                                                 \
         tB = nB;                                                                                 \
     }
@@ -507,6 +525,7 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
 #endif
 #undef GB_STAMP
 #undef GB_STAMP2
+#undef GB_STAMP3
 #undef GB_BUFLD
 #undef GB_CH
 #undef GB_TAP

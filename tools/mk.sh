@@ -1,8 +1,7 @@
 #!/bin/bash
 # incremental build of libmoonsr_hip.so + refresh of the content stamp (so that the GPU box does not rebuild it)
 cd /root/repo || exit 1
-make -C moonsuperresolution_amd/csrc -j8 2>&1 | grep -E "error|Error" -A3
-test -f moonsuperresolution_amd/csrc/libmoonsr_hip.so || exit 1
+if ! make -C moonsuperresolution_amd/csrc -j8 > /tmp/mk.log 2>&1; then grep -E "error" -A3 /tmp/mk.log | head -40; echo "BUILD FAILED"; exit 1; fi
 python - <<'PY'
 from moonsuperresolution_amd import _lib
 open(_lib.STAMP_PATH, "w").write(_lib.sources_hash() + "\n")
