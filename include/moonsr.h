@@ -275,6 +275,12 @@ int msr_op_conv3x3_f16c(msr_handle* h, const float* in_dev, const float* wt_dev,
 int msr_op_spade_gbr(msr_handle* h, const float* src_dev, int32_t S, const float* we_dev, const float* be_dev,
                      const float* wt_dev, const float* bias_dev, float* out_dev, int32_t B, int32_t r, int32_t N,
                      const float* aux_dev, int32_t aux_shift, const float* mean_dev, const float* std_dev, void* stream);
+/* Kernel-level entry of the head kernel (csrc/small_kernels.hip head_kernel), synchronous:
+ *   variant 0: leaky_relu(slope) -> UpSampling2D(2) -> Conv2D(1, 4, 'same') (networks.py:54-56), kernel_host = HWIO [4,4,C,1];
+ *   variant 1: Conv2DTranspose(1, 4, strides 2, 'same') -> tanh (pix2pix.py:53-57; pass slope = 1), kernel_host = [4,4,1,C]
+ *   (both are [kh][kw][C] in memory).  x_dev dense [B, r, r, C] (r, C multiples of 16); out_dev [B, 2r, 2r]. */
+int msr_op_head(msr_handle* h, const float* x_dev, const float* kernel_host, float bias, float* out_dev, int32_t B,
+                int32_t r, int32_t C, float slope, int32_t variant, void* stream);
 /* HOST helper: the fp32 -> fp8 e4m3 (OCP "fn", round to nearest even, saturating at 448) conversion msr_load_weight
  * applies to the weights of the fp8 mode, exposed so that it can be checked against an independent implementation. */
 int64_t msr_quantize_e4m3(const float* host, int64_t n, uint8_t* out);

@@ -72,6 +72,7 @@ SYMBOLS = [
     ("msr_op_conv3x3_f16c", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P,
                                       C.c_int32, _P, _P, C.c_int32, C.c_int32, _P]),
     ("msr_op_spade_gbr", C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P]),
+    ("msr_op_head", C.c_int, [_P, _P, _P, C.c_float, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P]),
     ("msr_quantize_e4m3", C.c_int64, [_P, C.c_int64, _P]),
     ("msr_op_conv3x3_fp8", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P,
                                      C.c_int32, _P, _P, C.c_int32, C.c_int32, _P]),

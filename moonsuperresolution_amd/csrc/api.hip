@@ -294,6 +294,39 @@ int upload_conv_weight(msr_handle* h, const std::string& key, const float* host,
     return upload(h, key, t.data(), floats);
 }
 
+// Effective per-parity taps of the head kernel, weff[py][px][dy + 1][dx + 1][C] (zero where a tap does not exist):
+//  * Conv2D(1, 4, 'same') applied to a nearest-2x up-sampled tensor (networks.py:54-56), kernel HWIO [4,4,C,1]: TF SAME for
+//    k = 4 pads 1 before / 2 after; output parity p reads up-sampled rows 2y + p - 1 + kh, i.e. half-resolution offsets
+//    {-1, 0, 0, +1} (p = 0) or {0, 0, +1, +1} (p = 1) for kh = 0..3 — taps that land on the same pixel are summed;
+//  * Conv2DTranspose(1, 4, strides 2, 'same') (pix2pix.py:53-57), kernel [4,4,1,C]: four stride-1 2 x 2 convolutions, one per
+//    output parity: out[2y + py][2x + px] = sum_{t,u} in[y - 1 + py + t][x - 1 + px + u] * W[kmap(py,t)][kmap(px,u)],
+//    kmap(0, .) = {3, 1}, kmap(1, .) = {2, 0}.
+std::vector<float> head_weff_upconv(const float* k44c, int C) {
+    std::vector<float> weff((size_t)36 * C, 0.f);
+    auto dmap = [](int parity, int k) { return parity == 0 ? (k == 0 ? 0 : k == 3 ? 2 : 1) : (k < 2 ? 1 : 2); };
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px)
+            for (int kh = 0; kh < 4; ++kh)
+                for (int kw = 0; kw < 4; ++kw) {
+                    float* dst = &weff[((((size_t)py * 2 + px) * 3 + dmap(py, kh)) * 3 + dmap(px, kw)) * C];
+                    const float* src = k44c + ((size_t)kh * 4 + kw) * C;
+                    for (int c = 0; c < C; ++c) dst[c] += src[c];
+                }
+    return weff;
+}
+std::vector<float> head_weff_transpose(const float* k44c, int C) {
+    static const int kmap[2][2] = {{3, 1}, {2, 0}};
+    std::vector<float> weff((size_t)36 * C, 0.f);
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px)
+            for (int t = 0; t < 2; ++t)
+                for (int u = 0; u < 2; ++u) {
+                    const float* src = k44c + ((size_t)kmap[py][t] * 4 + kmap[px][u]) * C;
+                    std::copy(src, src + C, &weff[((((size_t)py * 2 + px) * 3 + (py + t)) * 3 + (px + u)) * C]);
+                }
+    return weff;
+}
+
 struct ConvVariant { int tile; int wt_frag; int ksplit; };   // ksplit 0: conv_pick_ksplit decides (small tiles)
 ConvVariant pick_conv_variant(int B, int rout, int N, int stride, int epi, int prec, int cin);
 
@@ -697,16 +730,7 @@ int msr_load_weight(msr_handle* h, const char* name_c, const float* host, const 
             rc = upload(h, name, host, count);                       // conv_direct reads HWIO
         } else if (name == "p2p.last.kernel") {
             // [4,4,1,C] -> the head kernel's effective taps weff[py][px][dy][dx][C], offset dy-1 = py+t-1
-            const int C = (int)s[3];
-            std::vector<float> weff((size_t)36 * C, 0.f);
-            for (int py = 0; py < 2; ++py)
-                for (int px = 0; px < 2; ++px)
-                    for (int t = 0; t < 2; ++t)
-                        for (int u = 0; u < 2; ++u) {
-                            const float* src = host + ((size_t)kmap[py][t] * 4 + kmap[px][u]) * C;
-                            float* dst = &weff[((((size_t)py * 2 + px) * 3 + (py + t)) * 3 + (px + u)) * C];
-                            std::copy(src, src + C, dst);
-                        }
+            const std::vector<float> weff = head_weff_transpose(host, (int)s[3]);
             rc = upload(h, "p2p.last.weff", weff.data(), weff.size());
         } else if (ends_with(name, ".kernel") && name.find(".down") == std::string::npos) {
             // [kh,kw,Cout,Cin] is already K-contiguous per output channel: four parity images [2x2 taps][Cout][Cin]
@@ -748,18 +772,7 @@ int msr_load_weight(msr_handle* h, const char* name_c, const float* host, const 
         if (!rc) HIPCHK(h, hipMemcpy(d + (name == "enc.mean.bias" ? 0 : h->L), host, h->L * sizeof(float), hipMemcpyHostToDevice));
     } else if (name == "gen.head.kernel") {
         // effective per-parity taps of Conv2D(1,4,'same') applied to a nearest-2x up-sampled tensor
-        const int C = (int)s[2];
-        std::vector<float> weff((size_t)36 * C, 0.f);
-        auto dmap = [](int parity, int k) { return parity == 0 ? (k == 0 ? 0 : k == 3 ? 2 : 1) : (k < 2 ? 1 : 2); };
-        for (int py = 0; py < 2; ++py)
-            for (int px = 0; px < 2; ++px)
-                for (int kh = 0; kh < 4; ++kh)
-                    for (int kw = 0; kw < 4; ++kw) {
-                        const int dy = dmap(py, kh), dx = dmap(px, kw);
-                        float* dst = &weff[((((size_t)py * 2 + px) * 3 + dy) * 3 + dx) * C];
-                        const float* src = host + ((size_t)kh * 4 + kw) * C;
-                        for (int c = 0; c < C; ++c) dst[c] += src[c];
-                    }
+        const std::vector<float> weff = head_weff_upconv(host, (int)s[2]);
         rc = upload(h, "gen.head.weff", weff.data(), weff.size());
     } else if (name == "gen.head.bias") {
         h->host_small[name].assign(host, host + count);
@@ -1397,6 +1410,16 @@ int launch_all(msr_handle* h, const float* in_dev, const float* eps_dev, float* 
         bool any = false;
         for (auto& op : h->ops) any |= op.on_aux;
         if (any) {
+            // Under stream capture the fork must hang off a real node of the call's stream: with the event record as the very
+            // first captured operation the auxiliary branch becomes a second ROOT of the graph, and a replay was observed to
+            // start that branch before earlier work of the launch stream had finished (a torch copy into the input buffer:
+            // tests/test_gpu_generator.py::test_graph_replay_equals_eager, only after other processes had used the GPU).  A
+            // 16-byte memset node in front of the fork makes the graph single-rooted.
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (s && hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive) {
+                float* touch = D(h, "ws.aux_touch");
+                if (touch) HIPCHK(h, hipMemsetAsync(touch, 0, 16, s));
+            }
             HIPCHK(h, hipEventRecord(h->ev_fork, s));
             HIPCHK(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
             for (auto& op : h->ops) {
@@ -1716,6 +1739,23 @@ int msr_op_spade_gbr(msr_handle* h, const float* src_dev, int32_t S, const float
     if (ranges < 1) ranges = 1;
     hipError_t e = launch_conv_gbr(q, ranges, (hipStream_t)stream);
     if (e != hipSuccess) return fail(h, MSR_ERR_INVALID, "conv_gb_resident launch rejected: %s", hipGetErrorString(e));
+    return MSR_OK;
+}
+
+int msr_op_head(msr_handle* h, const float* x_dev, const float* kernel_host, float bias, float* out_dev, int32_t B,
+                int32_t r, int32_t C, float slope, int32_t variant, void* stream) {
+    if (!h) return MSR_ERR_INVALID;
+    if (!x_dev || !kernel_host || !out_dev || B < 1 || r < 16 || r % 16 || C < 16 || C % 16 || variant < 0 || variant > 1)
+        return fail(h, MSR_ERR_INVALID, "msr_op_head: bad argument (r and C multiples of 16, variant 0 | 1)");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const std::vector<float> weff = variant ? head_weff_transpose(kernel_host, C) : head_weff_upconv(kernel_host, C);
+    float* wd = nullptr;
+    HIPCHK(h, hipMalloc(&wd, weff.size() * sizeof(float)));
+    hipError_t e = hipMemcpy(wd, weff.data(), weff.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_head(x_dev, wd, bias, out_dev, B, r, C, slope, variant, 0, 0, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    hipFree(wd);
+    if (e != hipSuccess) return fail(h, MSR_ERR_DEVICE, "msr_op_head failed: %s", hipGetErrorString(e));
     return MSR_OK;
 }
 

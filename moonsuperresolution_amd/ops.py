@@ -387,3 +387,18 @@ def f16c_decode(img: torch.Tensor):
     h8 = b[..., 64:96].contiguous().view(torch.float8_e4m3fn).reshape(shp).double()
     l8 = b[..., 96:128].contiguous().view(torch.float8_e4m3fn).reshape(shp).double()
     return hi, h8, l8 / 2048.0
+
+
+def head(ctx: OpContext, x: torch.Tensor, kernel: "np.ndarray", bias: float, slope: float = 0.2, transpose_tanh: bool = False) -> torch.Tensor:
+    """One launch of the head kernel (msr_op_head): x dense [B, r, r, C] -> [B, 2r, 2r].  kernel [4, 4, C] float32 (host):
+    the Conv2D(1, 4, 'same') kernel applied after UpSampling2D(2) (networks.py:54-56), or with ``transpose_tanh`` the
+    Conv2DTranspose(1, 4, 2, 'same') kernel followed by tanh (pix2pix.py:53-57)."""
+    import numpy as np
+    B, r, _, Cc = x.shape
+    k = np.ascontiguousarray(kernel, dtype=np.float32)
+    assert k.shape == (4, 4, Cc)
+    out = torch.empty((B, 2 * r, 2 * r), dtype=torch.float32, device=x.device)
+    rc = ctx.lib.msr_op_head(ctx.h, x.contiguous().data_ptr(), k.ctypes.data_as(C.c_void_p), float(bias), out.data_ptr(), B, r, Cc,
+                             float(slope), 1 if transpose_tanh else 0, torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.raise_for(ctx.lib, ctx.h, rc, "msr_op_head")
+    return out

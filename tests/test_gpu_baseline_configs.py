@@ -114,6 +114,22 @@ def test_f16c_with_the_opt_in_fp6_cross_pieces_matches_oracle():
     assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("switch", ["MSR_GBR=0", "MSR_TILE_WALK=0", "MSR_PP_KSPLIT=0", "MSR_F16C_KSPLIT=0", "MSR_F16C_SW=0",
+                                    "MSR_F16C_SW=2"])
+def test_f16c_parity_under_every_documented_kernel_switch(switch):
+    """The behaviour-changing environment switches of the library (each read once per process: A/B dispatch of the conv kernels,
+    tile walk, K ranges) must all leave the default mode inside the parity bar: GauGAN(256, 16) against the oracle in a child
+    process per switch.  (MSR_F16C_FP6=1 has its own test above.)"""
+    import subprocess
+    import sys
+    k, v = switch.split("=")
+    env = dict(os.environ, **{k: v})
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "test_baseline_config_matches_oracle and f16c and 256-16"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("precision", ["f16c", "bf16x3", "fp32"])
 @pytest.mark.parametrize("variant", ["gaugan", "gaugan_no_kl"])
 def test_spade64_golden_in_both_precisions(hip_lib, variant, precision):

@@ -478,3 +478,44 @@ def test_spade_layer_resident_kernel(ctx, B, S, r, C, shift):
     assert float(((h8 - want).abs() / want.abs().clamp_min(2.0 ** -6)).max()) <= 2.0 ** -4 * 1.01 + 2e-3
     assert float(full[0][:, 0].abs().max()) == 0 and float(full[1][:, :, -1].abs().max()) == 0 and \
         float(full[0][:, -1].abs().max()) == 0 and float(full[2][:, :, 0].abs().max()) == 0        # the border stays zero
+
+
+def test_head_kernel_known_answers(ctx):
+    """Kernel-level KAT of the head on the HIP side (the oracle side: tests/test_oracle_generator.py):
+      * delta image -> the 1-before / 2-after SAME padding of Conv2D(1, 4) after UpSampling2D(2) (networks.py:55-56): a one
+        at half-resolution pixel (y, x), channel c lights the 2 x 2 up-sampled block, so out[Y][X] = sum of k[kh][kw][c] over
+        the taps with 2y <= Y - 1 + kh <= 2y + 1 (and the same in X);
+      * random tensors against torch's conv2d on the explicitly up-sampled, (1, 2)-padded input;
+      * the pix2pix variant: Conv2DTranspose(1, 4, 2, 'same') + tanh (pix2pix.py:53-57) against conv_transpose2d."""
+    from moonsuperresolution_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(3)
+    B, r, C = 2, 16, 32
+    k = torch.randn((4, 4, C), generator=g)
+    # delta probes (leaky relu is the identity on the positive delta)
+    for (y, x, c) in ((0, 0, 0), (15, 15, 31), (7, 3, 5), (0, 15, 17)):
+        xin = torch.zeros((B, r, r, C))
+        xin[1, y, x, c] = 1.0
+        got = ops.head(ctx, xin.cuda(), k.numpy(), 0.25).cpu()
+        want = torch.full((B, 2 * r, 2 * r), 0.25)
+        for Y in range(2 * r):
+            for X in range(2 * r):
+                acc = 0.0
+                for kh in range(4):
+                    for kw in range(4):
+                        if 2 * y <= Y - 1 + kh <= 2 * y + 1 and 2 * x <= X - 1 + kw <= 2 * x + 1:
+                            acc += float(k[kh, kw, c])
+                want[1, Y, X] += acc
+        assert torch.allclose(got, want, atol=1e-6), (y, x, c)
+    # random input: up-sample, pad (1 before, 2 after), correlate
+    xin = torch.randn((B, r, r, C), generator=g)
+    got = ops.head(ctx, xin.cuda(), k.numpy(), -0.1, slope=0.2).cpu()
+    a = torch.where(xin >= 0, xin, 0.2 * xin).double().permute(0, 3, 1, 2)
+    up = a.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    want = F.conv2d(F.pad(up, (1, 2, 1, 2)), k.double().permute(2, 0, 1)[None]).squeeze(1) - 0.1
+    assert rel_linf(got.numpy(), want.numpy()) <= 1e-5
+    # pix2pix: Conv2DTranspose(1, 4, strides 2, 'same') + tanh; Keras kernel [kh, kw, out = 1, in = C]
+    got = ops.head(ctx, xin.cuda(), k.numpy(), 0.05, slope=1.0, transpose_tanh=True).cpu()
+    wt = k.double().permute(2, 0, 1)[:, None]                                   # [in, out = 1, kh, kw]
+    full = F.conv_transpose2d(xin.double().permute(0, 3, 1, 2), wt, stride=2)       # [B, 1, 2r + 2, 2r + 2]
+    want = torch.tanh(full[:, 0, 1:-1, 1:-1] + 0.05)                             # TF 'same': crop 1 on each side
+    assert rel_linf(got.numpy(), want.numpy()) <= 1e-5

@@ -88,6 +88,7 @@ def test_graph_replay_equals_eager(Generator):
     x_other = torch.from_numpy(synthetic_patches(2, 64, 5)).cuda()
     ref = gen.forward_device(x).clone()
     ref_other = gen.forward_device(x_other).clone()
+    assert torch.equal(gen.forward_device(x_other), ref_other) and torch.equal(gen.forward_device(x), ref)   # eager is repeatable
     gen.use_graph(True)
     st = torch.cuda.Stream()
     outs = [torch.empty((2, 64, 64, 1), device="cuda") for _ in range(3)]
@@ -114,13 +115,52 @@ def test_graph_replay_equals_eager(Generator):
         gen.forward_device(xin, out=outs[0])
         st.synchronize()
         assert not torch.equal(outs[0], ref), "the replay did not see the new content of its input buffer (or did not run)"
-        assert torch.equal(outs[0], ref_other)
+        if not torch.equal(outs[0], ref_other):      # diagnostics: which side moved?
+            gen.use_graph(False)
+            again = gen.forward_device(x_other).clone()
+            again_xin = gen.forward_device(xin).clone()
+            st.synchronize()
+            raise AssertionError(f"graph replay != eager reference: eager(x_other) now == reference: {torch.equal(again, ref_other)}, "
+                                 f"eager(xin) now == reference: {torch.equal(again_xin, ref_other)}, eager(xin) == replay: "
+                                 f"{torch.equal(again_xin, outs[0])}, xin == x_other: {torch.equal(xin, x_other)}, "
+                                 f"max |replay - reference| = {float((outs[0] - ref_other).abs().max()):.3e}")
         gen.load(w2)
         y2 = gen.forward_device(x, out=outs[1]).clone()
         st.synchronize()
     gen.use_graph(False)
     assert torch.equal(gen.forward_device(x), y2) and not torch.equal(y2, ref)
     gen.close()
+
+
+def test_forward_gated_equals_plain_forward(Generator):
+    """msr_forward_gated (include/moonsr.h): two handles on two streams, each call's matrix-bound part gated on the event the
+    previous call (on the other handle) recorded at its end — the software pipeline of the tile loop (MSR_TILER_GATED).
+    Results must equal plain msr_forward bit for bit, whatever the interleaving."""
+    w = make_weights("gaugan", 64, seed=1234, bias_scale=0.05)
+    eps = make_latent_noise(2, 256, 7)
+    g0 = Generator(64, 2, variant="gaugan", weights=w, eps=eps)
+    g1 = g0.clone()
+    xs = [torch.from_numpy(synthetic_patches(2, 64, seed)).cuda() for seed in range(6)]
+    want = [g0.forward_device(x).clone() for x in xs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [torch.empty((2, 64, 64, 1), device="cuda") for _ in xs]
+    gate = None
+    for i, x in enumerate(xs):
+        g, st = (g0, g1)[i & 1], streams[i & 1]
+        with torch.cuda.stream(st):
+            g.forward_device(x, out=outs[i], gate=gate)
+            gate = torch.cuda.Event()
+            gate.record(st)
+    torch.cuda.synchronize()
+    for o, ref in zip(outs, want):
+        assert torch.equal(o, ref)
+    # a gate that has long fired, and no gate at all, on the same handle
+    ev = torch.cuda.Event()
+    ev.record()
+    torch.cuda.synchronize()
+    assert torch.equal(g1.forward_device(xs[0], gate=ev), want[0]) and torch.equal(g1.forward_device(xs[1]), want[1])
+    g0.close(); g1.close()
 
 
 def test_cnn_variant_equals_no_kl(Generator):
