@@ -179,6 +179,14 @@ int msr_stitch_tile(msr_handle* h, const float* pred_dev, const int32_t* key_dev
  * each hold part of the patches covering a pixel can combine them. */
 int msr_stitch_partial(msr_handle* h, const float* pred_dev, const int32_t* key_dev, const float* dmm_dev, int32_t n,
                        int32_t tile_size, int32_t stride, float* wsum_dev, float* mean_dev, float* s_dev, void* stream);
+/* msr_stitch_partial writing IN PLACE into a T x T window of larger accumulator images (row pitch `pitch` >= tile_size
+ * elements) and, with resume != 0, continuing the running update from what the window already holds instead of from zero:
+ * the banded form of the halo mode (moonsuperresolution_amd/halo.py) — a rank generates its patch rows band by band (in
+ * generation order), accumulates each band into the canvas rows it reaches and frees its predictions.  The sequence of
+ * updates per pixel is the all-at-once sequence, so the result does not depend on the band size, bit for bit. */
+int msr_stitch_accumulate(msr_handle* h, const float* pred_dev, const int32_t* key_dev, const float* dmm_dev, int32_t n,
+                          int32_t tile_size, int32_t stride, float* wsum_dev, float* mean_dev, float* s_dev, int32_t pitch,
+                          int32_t resume, void* stream);
 /* Pairwise (Chan) combine of two sets of accumulators of the same `count` pixels — a = the rank with the earlier patch
  * rows, b = the later one, or b == NULL — followed by rebuildTile's finalisation (good = w_sum > 0,
  * std = sqrt(S / w_sum), no_value where not good; process_full_tiles.py:409-413). */

@@ -53,6 +53,7 @@ SYMBOLS = [
                                       _P, _P, _P, _P]),
     ("msr_stitch_tile", C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, _P, _P, _P]),
     ("msr_stitch_partial", C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    ("msr_stitch_accumulate", C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, _P]),
     ("msr_halo_merge", C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_float, _P, _P, _P, _P]),
     ("msr_set_blend_window", C.c_int, [_P, _P, C.c_int32]),
     ("msr_resize_area", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P]),

@@ -1974,7 +1974,7 @@ static int default_window(msr_handle* h) {
 
 static int stitch_impl(msr_handle* h, const float* pred, const int32_t* key, const float* dmm, int32_t n,
                        int32_t tile_size, int32_t stride, float no_value, int32_t as_implemented, float* mean,
-                       float* stdv, uint8_t* good, float* wsum_partial, void* stream) {
+                       float* stdv, uint8_t* good, float* wsum_partial, void* stream, int pitch = 0, int resume = 0) {
     if (tile_size <= 0 || stride <= 0 || stride > h->S)
         return fail(h, MSR_ERR_INVALID, "msr_stitch_tile: tile_size %d / stride %d invalid for image_size %d", tile_size,
                     stride, h->S);
@@ -1987,7 +1987,7 @@ static int stitch_impl(msr_handle* h, const float* pred, const int32_t* key, con
         h->stitch_grid_cap = NG * NG;
     }
     HIPCHK(h, launch_stitch_tile(pred, key, dmm, n, h->S, tile_size, stride, no_value, as_implemented, h->window,
-                                 h->stitch_grid, mean, stdv, good, (hipStream_t)stream, wsum_partial));
+                                 h->stitch_grid, mean, stdv, good, (hipStream_t)stream, wsum_partial, pitch, resume));
     return MSR_OK;
 }
 
@@ -2006,6 +2006,16 @@ int msr_stitch_partial(msr_handle* h, const float* pred, const int32_t* key, con
     if (!wsum || !mean || !s_acc || n < 0 || (n > 0 && (!pred || !key || !dmm)))
         return fail(h, MSR_ERR_INVALID, "msr_stitch_partial: null pointer");
     return stitch_impl(h, pred, key, dmm, n, tile_size, stride, 0.f, /*as_implemented=*/0, mean, s_acc, nullptr, wsum, stream);
+}
+
+int msr_stitch_accumulate(msr_handle* h, const float* pred, const int32_t* key, const float* dmm, int32_t n,
+                          int32_t tile_size, int32_t stride, float* wsum, float* mean, float* s_acc, int32_t pitch,
+                          int32_t resume, void* stream) {
+    if (!h) return MSR_ERR_INVALID;
+    if (!wsum || !mean || !s_acc || n < 0 || pitch < tile_size || (n > 0 && (!pred || !key || !dmm)))
+        return fail(h, MSR_ERR_INVALID, "msr_stitch_accumulate: bad argument (pitch >= tile_size)");
+    return stitch_impl(h, pred, key, dmm, n, tile_size, stride, 0.f, /*as_implemented=*/0, mean, s_acc, nullptr, wsum, stream,
+                       pitch, resume ? 1 : 0);
 }
 
 int msr_halo_merge(msr_handle* h, const float* wa, const float* ma, const float* sa, const float* wb, const float* mb,

@@ -407,7 +407,9 @@ hipError_t launch_compact_patches(const uint8_t* valid, const int* ox, const int
                                   int* key, float* dmm, int* meta, hipStream_t s);
 hipError_t launch_stitch_tile(const float* pred, const int* key, const float* dmm, int n, int S, int T, int stride,
                               float no_value, int as_implemented, const double* window, int* grid_ws,
-                              float* mean, float* stdv, uint8_t* good, hipStream_t s, float* wsum_partial = nullptr);
+                              float* mean, float* stdv, uint8_t* good, hipStream_t s, float* wsum_partial = nullptr,
+                              int pitch = 0, int resume = 0);   // partial output only: row pitch of the three accumulator
+                                                                // images (0 = T), resume = start from their current content
 hipError_t launch_halo_merge(const float* wa, const float* ma, const float* sa, const float* wb, const float* mb,
                              const float* sb, long n, float no_value, float* mean, float* stdv, uint8_t* good,
                              hipStream_t s);

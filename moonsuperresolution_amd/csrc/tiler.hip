@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(256) stitch_tile_kernel(const float* __restric
                                                           int stride, float no_value, int as_implemented,
                                                           const double* __restrict__ window, float* __restrict__ mean_o,
                                                           float* __restrict__ std_o, uint8_t* __restrict__ good_o,
-                                                          float* __restrict__ wsum_o) {
+                                                          float* __restrict__ wsum_o, int pitch, int resume) {
     const int tx = blockIdx.x * 16 + (threadIdx.x & 15);
     const int ty = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (tx >= T || ty >= T) return;
@@ -219,7 +219,12 @@ __global__ void __launch_bounds__(256) stitch_tile_kernel(const float* __restric
     auto lo_idx = [&](int a) { int v = a - S + purge + 1; return v <= 0 ? 0 : (v + stride - 1) / stride; };
     auto hi_idx = [&](int a) { int v = a - purge; return v < 0 ? -1 : min(v / stride, NG - 1); };
     const int gy0 = lo_idx(ay), gy1 = hi_idx(ay), gx0 = lo_idx(ax), gx1 = hi_idx(ax);
+    const size_t o = (size_t)ty * pitch + tx;
     float w_sum = 0.f, mean = 0.f, s_acc = 0.f;
+    if (resume) {      // halo mode, banded: continue the running update where the previous band of patch rows left it (bands
+                       // come in generation order, so the sequence of updates per pixel is the all-at-once sequence)
+        w_sum = wsum_o[o]; mean = mean_o[o]; s_acc = std_o[o];
+    }
     for (int gy = gy0; gy <= gy1; ++gy) {
         const int py = ay - gy * stride;
         for (int gx = gx0; gx <= gx1; ++gx) {
@@ -239,7 +244,6 @@ __global__ void __launch_bounds__(256) stitch_tile_kernel(const float* __restric
             mean = mean_new;
         }
     }
-    const size_t o = (size_t)ty * T + tx;
     if (wsum_o) {      // halo mode: the raw accumulators (w_sum, mean, S) of this rank's patches, merged later
         wsum_o[o] = w_sum; mean_o[o] = mean; std_o[o] = s_acc;
         return;
@@ -253,14 +257,15 @@ __global__ void __launch_bounds__(256) stitch_tile_kernel(const float* __restric
 
 hipError_t launch_stitch_tile(const float* pred, const int* key, const float* dmm, int n, int S, int T, int stride,
                               float no_value, int as_implemented, const double* window, int* grid_ws, float* mean,
-                              float* stdv, uint8_t* good, hipStream_t s, float* wsum_partial) {
+                              float* stdv, uint8_t* good, hipStream_t s, float* wsum_partial, int pitch, int resume) {
     const int NG = (T + S - 1) / stride;   // len(range(0, T + S - stride, stride))
     hipError_t e = hipMemsetAsync(grid_ws, 0xFF, sizeof(int) * NG * NG, s);
     if (e != hipSuccess) return e;
     if (n > 0) stitch_grid_kernel<<<(n + 255) / 256, 256, 0, s>>>(key, n, stride, NG, grid_ws);
     stitch_tile_kernel<<<dim3((T + 15) / 16, (T + 15) / 16), 256, 0, s>>>(pred, dmm, grid_ws, NG, S, T, stride,
                                                                          no_value, as_implemented, window, mean,
-                                                                         stdv, good, wsum_partial);
+                                                                         stdv, good, wsum_partial, pitch > 0 ? pitch : T,
+                                                                         wsum_partial ? resume : 0);
     return hipGetLastError();
 }
 

@@ -127,6 +127,35 @@ def exchange_halo(send_down, send_up, recv_down_shape, recv_up_shape, rank: int,
     return from_down, from_up
 
 
+def exchange_halo_start(send_down, send_up, recv_down_shape, recv_up_shape, rank: int, world: int):
+    """exchange_halo split in two: the non-blocking sends / receives are started now, the returned ``wait()`` completes them
+    and returns (from_down, from_up).  What the caller launches in between (the finalisation of its interior rows) runs
+    beside the transfers."""
+    import torch
+    import torch.distributed as dist
+    ops, from_down, from_up = [], None, None
+    like = send_down if send_down is not None else send_up
+    keep = []
+    if rank > 0:
+        from_down = torch.empty(recv_down_shape, dtype=like.dtype, device=like.device)
+        keep.append(send_down.contiguous())
+        ops.append(dist.P2POp(dist.isend, keep[-1], rank - 1))
+        ops.append(dist.P2POp(dist.irecv, from_down, rank - 1))
+    if rank < world - 1:
+        from_up = torch.empty(recv_up_shape, dtype=like.dtype, device=like.device)
+        keep.append(send_up.contiguous())
+        ops.append(dist.P2POp(dist.isend, keep[-1], rank + 1))
+        ops.append(dist.P2POp(dist.irecv, from_up, rank + 1))
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+
+    def wait():
+        for req in reqs:
+            req.wait()
+        keep.clear()
+        return from_down, from_up
+    return wait
+
+
 def all_gather_var_rows(local, counts: Sequence[int]):
     """All-gather of row slabs whose row counts differ by rank (halo mode: ownership boundaries follow patch rows, not
     tiles): pad to the largest count, one all_gather_into_tensor, trim.  counts[r] = rows of rank r."""

@@ -14,8 +14,14 @@ Deviations from the reference (documented, inherent; oracle/tiler_ref.py::proces
   3. boundary-zone pixels are combined pairwise instead of sequentially: float32 rounding differs (~1e-7 relative).
 The exact, reference-identical multi-GPU mode is the tile-row sharding of distributed.process_map_sharded.
 
-Memory: a rank keeps the predictions of all its patches until it has stitched them (S * S * 4 bytes each: 34 k patches
-= 34 GB per rank for the 15000 x 70000 raster on 8 ranks at S = 512 — sized for 288 GB of HBM).
+Memory (round 3): a rank works through its patch rows in BANDS (``band_rows`` patch rows at a time, default sized to
+``band_bytes`` = 4 GiB of predictions): a band is generated, accumulated into the canvas rows it reaches — in place, block by
+block, with only the band's own keys (msr_stitch_accumulate: the running update resumes from what earlier bands left, so the
+result does not depend on the band size, bit for bit) — and its predictions are freed.  What stays resident is the rank's
+accumulator slab (3 float32 images of the canvas rows its patches reach: 2.1 GB for a 1/8 share of the 15000 x 70000 raster)
+plus one band; round 2 kept all predictions of the rank (34 GB at that size).
+Exchange: the two boundary-zone slabs go to the neighbours as non-blocking send / recv while the interior rows (reached by this
+rank's patches only) are finalised; the zones are finalised when the neighbours' slabs have arrived.
 """
 from __future__ import annotations
 
@@ -25,7 +31,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .distributed import exchange_halo, halo_zone_rows
+from .distributed import halo_zone_rows
 from .tiler import DEMSuperResolution
 
 
@@ -108,30 +114,27 @@ class HaloShardedSuperResolution(DEMSuperResolution):
             self.last_counts_halo = (nv, ncall)
             return preds, keys, dmm, nv
 
-    def _accumulate(self, preds, keys, dmm, nv: int, row_lo: int, row_hi: int):
-        """Accumulators (w_sum, mean, S) of the given patches for canvas rows [row_lo, row_hi), all canvas columns:
-        [3, row_hi - row_lo, Wp] float32.  Stitched block by block (T x T) with the gather kernel of the tile mode."""
+    def _accumulate_band(self, acc, y_b0: int, preds, keys, dmm, nv: int, band_lo: int, band_hi: int) -> None:
+        """Add the patches of one band (canvas rows [band_lo, band_hi) are the rows they reach) to the accumulator slab
+        ``acc`` [3, n_by * T, n_bx * T] whose row 0 is canvas row ``y_b0`` (a multiple of T): every T x T block the band
+        touches is continued in place from its current content, with the band's keys only."""
         T, S, s = self.tile_size, self.image_size, self.stride
         halo = S - s
         lib, h, dev = self._lib, self._h, self.device
-        hp, wp = self.dem_padded_shape
-        y_b0 = (row_lo // T) * T
-        n_by = (row_hi - y_b0 + T - 1) // T
-        n_bx = (wp + T - 1) // T
+        pitch = acc.shape[2]
+        by0, by1 = (band_lo - y_b0) // T, (band_hi - 1 - y_b0) // T
         with torch.cuda.device(dev):
-            acc = torch.zeros((3, n_by * T, n_bx * T), dtype=torch.float32, device=dev)
-            blk = torch.empty((3, T, T), dtype=torch.float32, device=dev)
-            for by in range(n_by):
-                for bx in range(n_bx):
+            for by in range(max(by0, 0), min(by1, acc.shape[1] // T - 1) + 1):
+                for bx in range(pitch // T):
                     y0, x0 = y_b0 + by * T, bx * T
                     # patch keys relative to the block's grid origin (x0 - halo, y0 - halo): accumulator coordinate =
                     # block pixel + halo, exactly the tile mode's geometry
                     rel = keys[:max(nv, 1)] - torch.tensor([x0 - halo, y0 - halo], dtype=torch.int32, device=dev)
-                    rc = lib.msr_stitch_partial(h, preds.data_ptr(), rel.data_ptr(), dmm.data_ptr(), nv, T, s,
-                                                blk[0].data_ptr(), blk[1].data_ptr(), blk[2].data_ptr(), self._stream())
-                    _lib.raise_for(lib, h, rc, "msr_stitch_partial")
-                    acc[:, by * T:(by + 1) * T, bx * T:(bx + 1) * T] = blk
-            return acc[:, row_lo - y_b0:row_hi - y_b0, :wp].contiguous()
+                    win = acc[:, by * T:(by + 1) * T, bx * T:(bx + 1) * T]
+                    rc = lib.msr_stitch_accumulate(h, preds.data_ptr(), rel.data_ptr(), dmm.data_ptr(), nv, T, s,
+                                                   win[0].data_ptr(), win[1].data_ptr(), win[2].data_ptr(), pitch, 1,
+                                                   self._stream())
+                    _lib.raise_for(lib, h, rc, "msr_stitch_accumulate")
 
     def _finalize(self, a, b=None):
         """msr_halo_merge over [3, rows, W] accumulators -> (mean, std, good)."""
@@ -153,13 +156,17 @@ class HaloShardedSuperResolution(DEMSuperResolution):
         return mean, std, good
 
     # ------------------------------------------------------------------------------------------------------------
-    def haloAccumulate(self, rank: int = 0, world: int = 1):
-        """Phase 1 (no communication): generate this rank's patch rows and accumulate them.  Returns the state
-        ``haloFinish`` takes: the accumulators of the canvas rows the rank's patches reach, what it must send to its
-        neighbours and the shapes of what it receives."""
+    def haloAccumulate(self, rank: int = 0, world: int = 1, band_rows: Optional[int] = None, band_bytes: int = 4 << 30,
+                       max_rows: int = 0):
+        """Phase 1 (no communication): generate this rank's patch rows band by band and accumulate them.  Returns the
+        state ``haloFinish`` takes: the accumulators of the canvas rows the rank's patches reach, what it must send to its
+        neighbours and the shapes of what it receives.  ``band_rows`` patch rows per band (default: as many as fit
+        ``band_bytes`` of predictions); ``max_rows`` > 0 stops after that many patch rows (benchmarks of a share of a
+        large raster: the accumulators of the rows not reached stay empty)."""
         if self.dem_padded is None or self.dem is not None:
             self.padInputs()
-        S = self.image_size
+        S, T = self.image_size, self.tile_size
+        p = S // 16
         hp, wp = self.dem_padded_shape
         ys, xs = self.patchGrid()
         zones = halo_zone_rows(ys, S, world)
@@ -169,9 +176,31 @@ class HaloShardedSuperResolution(DEMSuperResolution):
         own_hi = hp if z["own_hi"] is None else z["own_hi"]
         if (rank > 0 and own_lo < lo) or (rank < world - 1 and own_hi > hi):
             raise ValueError("halo mode needs overlapping patches (stride <= S/2 - S/16)")
-        preds, keys, dmm, nv = self._generate_rows(ys[z["g0"]:z["g1"]], xs)
-        acc = self._accumulate(preds, keys, dmm, nv, lo, hi)
-        del preds
+        my_ys = ys[z["g0"]:z["g1"]]
+        if band_rows is None:
+            band_rows = max(1, int(band_bytes // max(1, len(xs) * S * S * 4)))
+        y_b0 = (lo // T) * T
+        n_by = (hi - y_b0 + T - 1) // T
+        n_bx = (wp + T - 1) // T
+        nv_tot = nc_tot = 0
+        with torch.cuda.device(self.device):
+            slab = torch.zeros((3, n_by * T, n_bx * T), dtype=torch.float32, device=self.device)
+            done = 0
+            for b0 in range(0, len(my_ys), band_rows):
+                band = my_ys[b0:b0 + band_rows]
+                if max_rows and done + len(band) > max_rows:
+                    band = band[:max_rows - done]
+                if not band:
+                    break
+                preds, keys, dmm, nv = self._generate_rows(band, xs)
+                self._accumulate_band(slab, y_b0, preds, keys, dmm, nv, band[0] + p, band[-1] + S - p)
+                nv_tot += self.last_counts_halo[0]
+                nc_tot += self.last_counts_halo[1]
+                done += len(band)
+                del preds, keys, dmm                     # the band's predictions are not needed again
+            acc = slab[:, lo - y_b0:hi - y_b0, :wp]
+        self.last_counts_halo = (nv_tot, nc_tot)
+        self.last_band_rows = band_rows
         st = dict(rank=rank, world=world, acc=acc, lo=lo, hi=hi, own_lo=own_lo, own_hi=own_hi, wp=wp,
                   send_down=acc[:, :own_lo - lo] if rank > 0 else None,                     # rows [touch_lo, own_lo)
                   send_up=acc[:, own_hi - lo:] if rank < world - 1 else None,                # rows [own_hi, touch_hi)
@@ -179,46 +208,62 @@ class HaloShardedSuperResolution(DEMSuperResolution):
                   up_rows=max(0, own_hi - zones[rank + 1]["touch_lo"]) if rank < world - 1 else 0)
         return st
 
-    def haloFinish(self, st, from_down=None, from_up=None):
+    def haloFinish(self, st, from_down=None, from_up=None, *, exchange: Optional[Callable] = None):
         """Phase 2: combine the boundary zones with the neighbours' accumulators (from_down = rank - 1's rows
         [own_lo, own_lo + down_rows), its patches come first; from_up = rank + 1's rows [own_hi - up_rows, own_hi)) and
-        finalise.  Returns ((mean, std, good) for canvas rows [own_lo, own_hi), (own_lo, own_hi))."""
+        finalise.  With ``exchange`` (a callable returning (from_down, from_up), e.g. the ``wait`` of
+        distributed.exchange_halo_start) the interior rows are finalised FIRST and the exchange is waited for afterwards:
+        the transfer runs beside the interior kernels.
+        Returns ((mean, std, good) for canvas rows [own_lo, own_hi), (own_lo, own_hi))."""
         acc, lo, hi, own_lo, own_hi, wp = st["acc"], st["lo"], st["hi"], st["own_lo"], st["own_hi"], st["wp"]
-        down_rows = st["down_rows"] if from_down is not None else 0
-        up_rows = st["up_rows"] if from_up is not None else 0
         with torch.cuda.device(self.device):
             mean = torch.full((own_hi - own_lo, wp), self.no_value, dtype=torch.float32, device=self.device)
             std = torch.full_like(mean, self.no_value)
             good = torch.zeros((own_hi - own_lo, wp), dtype=torch.uint8, device=self.device)
 
             def put(r0, r1, a, b=None):
-                if r1 > r0:
-                    m, s_, g = self._finalize(a, b)
-                    mean[r0 - own_lo:r1 - own_lo], std[r0 - own_lo:r1 - own_lo], good[r0 - own_lo:r1 - own_lo] = m, s_, g
+                # in slabs of T rows: the accumulator is a view with the slab's pitch, so each piece is compacted for
+                # the merge kernel — T rows at a time instead of a second copy of the whole interior
+                for c0 in range(r0, r1, self.tile_size):
+                    c1 = min(r1, c0 + self.tile_size)
+                    m, s_, g = self._finalize(a[:, c0 - r0:c1 - r0], None if b is None else b[:, c0 - r0:c1 - r0])
+                    mean[c0 - own_lo:c1 - own_lo], std[c0 - own_lo:c1 - own_lo], good[c0 - own_lo:c1 - own_lo] = m, s_, g
 
-            d_end, u_beg = own_lo + down_rows, own_hi - up_rows
-            if down_rows:                                        # zone shared with the rank below
-                put(own_lo, d_end, from_down, acc[:, own_lo - lo:d_end - lo])
-            m0, m1 = max(lo, d_end), min(hi, u_beg)              # rows only my patches reach
+            # rows only my patches reach: independent of the neighbours (the zone row counts are known from the geometry)
+            d_end = own_lo + (st["down_rows"] if st["rank"] > 0 else 0)
+            u_beg = own_hi - (st["up_rows"] if st["rank"] < st["world"] - 1 else 0)
+            if exchange is None and from_down is None:
+                d_end = own_lo
+            if exchange is None and from_up is None:
+                u_beg = own_hi
+            m0, m1 = max(lo, d_end), min(hi, u_beg)
             put(m0, m1, acc[:, m0 - lo:m1 - lo])
-            if up_rows:                                          # zone shared with the rank above
+            if exchange is not None:
+                from_down, from_up = exchange()
+            if d_end > own_lo:                                   # zone shared with the rank below
+                put(own_lo, d_end, from_down, acc[:, own_lo - lo:d_end - lo])
+            if own_hi > u_beg:                                   # zone shared with the rank above
                 put(u_beg, own_hi, acc[:, u_beg - lo:own_hi - lo], from_up)
         return (mean, std, good), (own_lo, own_hi)
 
     def processMapHalo(self, img: Optional[np.ndarray] = None, dem: Optional[np.ndarray] = None, rank: int = 0,
-                       world: int = 1, exchange: Optional[Callable] = None):
-        """This rank's share of the map in halo mode: accumulate, exchange the boundary zones with the neighbours
-        (``exchange`` defaults to distributed.exchange_halo: torch.distributed send / recv, RCCL on the GPUs), finish."""
+                       world: int = 1, exchange: Optional[Callable] = None, band_rows: Optional[int] = None):
+        """This rank's share of the map in halo mode: accumulate band by band, start the exchange of the boundary zones
+        with the neighbours (non-blocking send / recv: distributed.exchange_halo_start, RCCL on the GPUs), finalise the
+        interior rows beside it, then the zones.  ``exchange``: a blocking replacement with exchange_halo's signature."""
         if img is not None:
             self.setImages(img, dem)
-        st = self.haloAccumulate(rank, world)
-        from_down = from_up = None
-        if world > 1:
-            torch.cuda.current_stream(self.device).synchronize()
-            wp = st["wp"]
-            from_down, from_up = (exchange or exchange_halo)(st["send_down"], st["send_up"], (3, st["down_rows"], wp),
-                                                             (3, st["up_rows"], wp), rank, world)
-        return self.haloFinish(st, from_down, from_up)
+        st = self.haloAccumulate(rank, world, band_rows=band_rows)
+        if world == 1:
+            return self.haloFinish(st)
+        torch.cuda.current_stream(self.device).synchronize()      # the slabs are complete before they are sent
+        wp = st["wp"]
+        shapes = ((3, st["down_rows"], wp), (3, st["up_rows"], wp))
+        if exchange is not None:
+            return self.haloFinish(st, *exchange(st["send_down"], st["send_up"], shapes[0], shapes[1], rank, world))
+        from .distributed import exchange_halo_start
+        wait = exchange_halo_start(st["send_down"], st["send_up"], shapes[0], shapes[1], rank, world)
+        return self.haloFinish(st, exchange=wait)
 
     def cropHalo(self, slabs: Sequence[Tuple[Tuple[torch.Tensor, torch.Tensor, torch.Tensor], Tuple[int, int]]]):
         """Assemble per-rank slabs (in rank order) into the final rasters cropped to the input extent: final pixel

@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--halo", action="store_true",
                     help="patch-row-sharded mode (halo.py): every patch position generated once, neighbour exchange of "
                          "the boundary-zone accumulators over send / recv; NOT reference-identical (see halo.py)")
+    ap.add_argument("--max-rows", type=int, default=0, help="halo mode: stop after this many patch rows of the shard (0 = all)")
+    ap.add_argument("--band-rows", type=int, default=0, help="halo mode: patch rows per band (0 = what fits --band-gib of predictions)")
+    ap.add_argument("--band-gib", type=float, default=2.0, help="halo mode: predictions kept at a time, GiB")
     ap.add_argument("--passes", type=int, default=1, help="run the shard this many times; the last pass is reported")
     ap.add_argument("--dump", default="", help="rank 0 writes the finished products (mean, std, good) to this .npz: the gathered "
                                                "rows with --gather, else its own rows (tests compare them across process counts)")
@@ -133,18 +136,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        st = hs.haloAccumulate(shard_rank, shard_world)
+        torch.cuda.reset_peak_memory_stats()
+        st = hs.haloAccumulate(shard_rank, shard_world, band_rows=args.band_rows or None,
+                               band_bytes=int(args.band_gib * (1 << 30)), max_rows=args.max_rows)
         torch.cuda.synchronize()
         t_acc = time.perf_counter() - t0
-        from_down = from_up = None
         if world > 1:
-            from moonsuperresolution_amd.distributed import exchange_halo
-            from_down, from_up = exchange_halo(st["send_down"], st["send_up"], (3, st["down_rows"], st["wp"]),
-                                               (3, st["up_rows"], st["wp"]), rank, world)
-            torch.cuda.synchronize()
-        t_ex = time.perf_counter() - t0 - t_acc
-        (m, sd, g), (own_lo, own_hi) = hs.haloFinish(st, from_down, from_up)
+            # the zone slabs travel while the interior rows are finalised; the wait sits inside haloFinish
+            from moonsuperresolution_amd.distributed import exchange_halo_start
+            wait = exchange_halo_start(st["send_down"], st["send_up"], (3, st["down_rows"], st["wp"]),
+                                       (3, st["up_rows"], st["wp"]), rank, world)
+            (m, sd, g), (own_lo, own_hi) = hs.haloFinish(st, exchange=wait)
+        else:
+            (m, sd, g), (own_lo, own_hi) = hs.haloFinish(st)
         torch.cuda.synchronize()
+        t_ex = time.perf_counter() - t0 - t_acc
+        free_b, total_b = torch.cuda.mem_get_info()
         if world > 1 and args.gather:
             ys, _ = hs.patchGrid()
             zones = halo_zone_rows(ys, S, world)
@@ -167,7 +174,10 @@ def main():
                 "metric": "raster end-to-end, halo mode (every patch position generated once; not reference-identical)",
                 "n_gpus": world, "raster": [args.rows, args.cols], "image_size": S, "stride": s, "batch_size": B,
                 "shard": [shard_rank, shard_world], "patches": int(tot[0]), "generator_calls": int(tot[1]),
-                "seconds": float(mx[0]), "seconds_accumulate_rank0": t_acc, "seconds_exchange_rank0": t_ex,
+                "seconds": float(mx[0]), "seconds_accumulate_rank0": t_acc, "seconds_exchange_and_finalize_rank0": t_ex,
+                "band_rows": hs.last_band_rows, "max_rows": args.max_rows,
+                "peak_torch_allocated_gb_rank0": torch.cuda.max_memory_allocated() / 1e9,
+                "device_memory_in_use_gb_rank0": (total_b - free_b) / 1e9,
                 "patches_per_s": float(tot[0]) / float(mx[0]),
                 "tiles512_per_s": float(tot[1]) * B * (S / 512.0) ** 2 / float(mx[0]),
                 "own_rows_rank0": [own_lo, own_hi], "zone_bytes_sent_rank0":

@@ -113,9 +113,9 @@ def test_uneven_rows_three_ranks_layout():
 
 
 # ---- halo mode: the neighbour exchange and the variable-row gather over gloo, on the oracle's accumulators ----
-def _halo_worker(rank, world, port, q):
+def _halo_worker(rank, world, port, q, overlapped=False):
     from oracle import tiler_ref
-    from moonsuperresolution_amd.distributed import all_gather_var_rows, exchange_halo, halo_zone_rows
+    from moonsuperresolution_amd.distributed import all_gather_var_rows, exchange_halo, exchange_halo_start, halo_zone_rows
     from tests.helpers import synthetic_raster
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -135,8 +135,13 @@ def _halo_worker(rank, world, port, q):
     send_up = torch.from_numpy(acc[:, own_hi:hi].copy()) if rank < world - 1 else None
     down_rows = zones[rank - 1]["touch_hi"] - own_lo if rank > 0 else 0
     up_rows = own_hi - zones[rank + 1]["touch_lo"] if rank < world - 1 else 0
-    from_down, from_up = exchange_halo(send_down, send_up, (3, down_rows, wp), (3, up_rows, wp), rank, world)
-    mine = [a[own_lo:own_hi].copy() for a in acc]
+    if overlapped:     # the non-blocking form halo.py uses: start, do the rank's own work, wait
+        wait = exchange_halo_start(send_down, send_up, (3, down_rows, wp), (3, up_rows, wp), rank, world)
+        mine = [a[own_lo:own_hi].copy() for a in acc]
+        from_down, from_up = wait()
+    else:
+        from_down, from_up = exchange_halo(send_down, send_up, (3, down_rows, wp), (3, up_rows, wp), rank, world)
+        mine = [a[own_lo:own_hi].copy() for a in acc]
     if from_down is not None:
         m = tiler_ref.chan_merge(tuple(from_down.numpy()), tuple(a[:down_rows] for a in mine))
         for a, b in zip(mine, m):
@@ -156,10 +161,11 @@ def _halo_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_halo_exchange_over_gloo_equals_oracle(world):
-    """exchange_halo (send / recv of the boundary zones) + all_gather_var_rows on `world` gloo ranks reproduce the
-    oracle's halo mode run in one process with the same number of simulated ranks, bit for bit."""
+@pytest.mark.parametrize("world,overlapped", [(2, False), (3, False), (3, True)])
+def test_halo_exchange_over_gloo_equals_oracle(world, overlapped):
+    """exchange_halo (send / recv of the boundary zones; overlapped = exchange_halo_start ... wait) + all_gather_var_rows on
+    `world` gloo ranks reproduce the oracle's halo mode run in one process with the same number of simulated ranks, bit
+    for bit."""
     from oracle import tiler_ref
     from tests.helpers import synthetic_raster
     img, dem = synthetic_raster(260, 150, 31, hole=(100, 130, 40, 90))
@@ -170,7 +176,7 @@ def test_halo_exchange_over_gloo_equals_oracle(world):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, q, overlapped)) for r in range(world)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=300) for _ in range(world))

@@ -26,10 +26,10 @@ def f32_identity(x, training=False):
     return np.asarray(x, np.float32)
 
 
-def run_halo(d, img, dem, world):
+def run_halo(d, img, dem, world, band_rows=None):
     """`world` ranks simulated on one GPU: phase 1 per rank, the zone hand-over done in-process, phase 2 per rank."""
     d.setImages(img, dem)
-    states = [d.haloAccumulate(r, world) for r in range(world)]
+    states = [d.haloAccumulate(r, world, band_rows=band_rows) for r in range(world)]
     slabs = []
     for r, st in enumerate(states):
         from_down = states[r - 1]["send_up"] if r > 0 else None
@@ -67,6 +67,40 @@ def test_identity_model_halo_mode(hip_lib, S, stride, B, T, shape, hole):
         assert np.array_equal(got[2], one[2])
         scale = float(np.abs(one[0][ok]).max())
         assert float(np.abs(got[0][ok] - one[0][ok]).max()) <= 1e-6 * scale
+    # banded accumulation (the sliding window over patch rows): the rank's patch rows in bands of 1, 2 and 3 rows, each
+    # band continued in place from what the earlier bands left -> the same bits as all rows at once, for 1 and 3 ranks
+    ys, _ = d.patchGrid()
+    for world, band_rows in ((1, 1), (1, 3), (3, 1), (3, 2)):
+        assert -(-(len(ys) // world) // band_rows) >= 3                    # at least three bands per rank
+        got = run_halo(d, img, dem, world, band_rows=band_rows)
+        ref = one if world == 1 else tiler_ref.process_map_halo(img, dem, f32_identity, S, stride, B, T, NOVAL, world=world)
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b, equal_nan=True), (world, band_rows)
+    d.close()
+
+
+def test_halo_overlapped_finish_and_max_rows(hip_lib):
+    """haloFinish(exchange=wait) — interior rows finalised before the neighbours' slabs are taken — gives the bits of the
+    blocking order; max_rows stops after that many patch rows (the rest of the rank's accumulator stays empty)."""
+    from moonsuperresolution_amd import DSRConfig, HaloShardedSuperResolution
+    img, dem = synthetic_raster(300, 200, 5)
+    d = HaloShardedSuperResolution(DSRConfig(image_size=64, stride=16, batch_size=4, tile_size=128), model=f32_identity)
+    d.setImages(img, dem)
+    states = [d.haloAccumulate(r, 3, band_rows=2) for r in range(3)]
+    st = states[1]
+    a = d.haloFinish(st, states[0]["send_up"], states[2]["send_down"])
+    b = d.haloFinish(st, exchange=lambda: (states[0]["send_up"], states[2]["send_down"]))
+    for x, y in zip(a[0], b[0]):
+        assert torch.equal(x, y)
+    full = d.haloAccumulate(0, 1, band_rows=2)
+    part = d.haloAccumulate(0, 1, band_rows=2, max_rows=5)
+    ys, _ = d.patchGrid()
+    p = 64 // 16
+    reach = ys[4] + 64 - p                                   # canvas rows the first five patch rows reach
+    untouched_from = ys[5] + p                               # rows below this line got every patch they will ever get
+    lo = full["lo"]                                          # accumulator row 0 is canvas row lo
+    assert torch.equal(part["acc"][:, :untouched_from - lo], full["acc"][:, :untouched_from - lo])
+    assert float(part["acc"][0, reach - lo:].abs().max()) == 0.0 and float(full["acc"][0, reach - lo:].abs().max()) > 0.0
     d.close()
 
 
