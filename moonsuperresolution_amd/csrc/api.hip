@@ -936,6 +936,16 @@ Op moments_op(const float* x, int G, int P, int C, float eps, float* mean, float
     return op;
 }
 
+// A split-K conv whose output feeds a normalisation takes the moments in its own epilogue (splitk_epilogue_mom_kernel).
+bool fuse_moments_into_splitk(Op& cv, int G, float eps, float* mean, float* stdv) {
+    if (cv.type != OP_CONV || cv.conv.ksplit <= 1 || (cv.epi != EPI_BIAS && cv.epi != EPI_RES) || cv.conv.N % 32)
+        return false;
+    static const bool off = std::getenv("MSR_FUSE_MOMENTS") && std::atoi(std::getenv("MSR_FUSE_MOMENTS")) == 0;
+    if (off) return false;
+    cv.conv.mom_mean = mean; cv.conv.mom_std = stdv; cv.conv.mom_eps = eps; cv.conv.mom_G = G;
+    return true;
+}
+
 int plan_spade(msr_handle* h) {
     const int S = h->S, B = h->B, L = h->L;
     char n[160];
@@ -971,8 +981,9 @@ int plan_spade(msr_handle* h) {
         snprintf(n, sizeof n, "enc.ds%d.kernel", i);
         Op cv = conv_op(e_in, need(n), zero_bias, B, r, c, 2, EPI_BIAS, h->prec);
         set_out_dense(cv.conv, raw, r, c);
+        const bool fused = fuse_moments_into_splitk(cv, B, 1e-3f, mean, stdv);
         h->ops.push_back(cv);
-        h->ops.push_back(moments_op(raw, B, r * r, c, 1e-3f, mean, stdv));
+        if (!fused) h->ops.push_back(moments_op(raw, B, r * r, c, 1e-3f, mean, stdv));
         mom_need(B, r * r, c);
         Op na; na.type = OP_NORMACT;
         snprintf(n, sizeof n, "enc.ds%d.in.gamma", i); na.na.gamma = need(n);
@@ -1152,8 +1163,10 @@ int plan_spade(msr_handle* h) {
         };
         // moments of a conv output: finalize the conv's own slabs if it emitted them, else read the tensor
         auto push_moments = [&](const float* x, int P, int C, float* mean, float* stdv) {
-            const Op& last = h->ops.back();
-            if (last.type == OP_CONV && last.stat_slabs > 0) {
+            Op& last = h->ops.back();
+            if (fuse_moments_into_splitk(last, 1, 1e-5f, mean, stdv)) {
+                mom_need(1, P, C);
+            } else if (last.type == OP_CONV && last.stat_slabs > 0) {
                 Op op; op.type = OP_MOMENTS_SLABS;
                 op.mom = {nullptr, 1, last.stat_slabs, C, 1e-5f, mean, stdv};
                 h->ops.push_back(op);
@@ -1470,6 +1483,7 @@ int launch_all(msr_handle* h, const float* in_dev, const float* eps_dev, float* 
                 fam = FAM_CONV;
                 ConvParams cp = op.conv;
                 cp.partial = h->conv_partial;
+                cp.mom_partial = h->mom_partial;
                 cp.stat_partial = op.stat_slabs > 0 ? h->stat_ws : nullptr;
                 e = launch_conv_igemm(cp, op.epi, op.tile, s);
                 break;

@@ -1960,6 +1960,7 @@ static hipError_t launch_cfg(const ConvParams& p, int epi, hipStream_t s) {
     if (p.ksplit > 1) {
         if (!p.partial || epi == EPI_PARTIAL) return hipErrorInvalidValue;
         conv_igemm<WM, WN, MT, NT, BKC, EPI_PARTIAL, PREC><<<g.tiles_mn * p.ksplit, C::NTHR, C::LDS, s>>>(p, g);
+        if (p.mom_mean) return launch_splitk_epilogue_mom(p, epi, s);      // epilogue + the output's moments, one launch
         const int Cout = epi == EPI_SPADE ? p.N / 2 : p.N;
         long eb = ((long)p.B * p.Hout * p.Wout * (Cout / 4) + 255) / 256;
         if (eb > 4096) eb = 4096;
@@ -1998,6 +1999,7 @@ static hipError_t launch_bf16x3(const ConvParams& p, int epi, hipStream_t s) {
     if (p.ksplit > 1) {
         if (!p.partial || epi == EPI_PARTIAL) return hipErrorInvalidValue;
         conv_igemm_bf16x3<WM, WN, MT, NT, EPI_PARTIAL><<<grid, C::NTHR, C::LDS, s>>>(p, g);
+        if (p.mom_mean) return launch_splitk_epilogue_mom(p, epi, s);      // epilogue + the output's moments, one launch
         const int Cout = epi == EPI_SPADE ? p.N / 2 : p.N;
         long eb = ((long)p.B * p.Hout * p.Wout * (Cout / 4) + 255) / 256;
         if (eb > 4096) eb = 4096;
@@ -2071,6 +2073,7 @@ static hipError_t launch_pp(const ConvParams& p, int epi, hipStream_t s) {
         } else {
             conv_igemm_bf16x3_pp<EPI_PARTIAL, PP_BF16X3><<<grid, 512, PP_LDS, s>>>(p, g);
         }
+        if (p.mom_mean) return launch_splitk_epilogue_mom(p, epi, s);      // epilogue + the output's moments, one launch
         const int Cout = epi == EPI_SPADE ? p.N / 2 : p.N;
         long eb = ((long)p.B * p.Hout * p.Wout * (Cout / 4) + 255) / 256;
         if (eb > 4096) eb = 4096;

@@ -67,7 +67,16 @@ struct ConvParams {
                                   // four bytes of the word (the MFMA's scale operand)
     int wt_frag;                  // PREC_BF16X3: weights are in MFMA-fragment order (conv_igemm_bf16x3, B in VGPRs)
                                   // instead of the split-bf16 image of [tap][N][Cin] (LDS-staged B)
+    // EPI_BIAS / EPI_RES, ksplit > 1, mom_mean != nullptr: the split-K epilogue also produces the moments of the output
+    // (splitk_epilogue_mom_kernel): mom_G = 1 over the whole batch (a SPADE input), mom_G > 1 per sample (instance norm)
+    double* mom_partial = nullptr;
+    float* mom_mean = nullptr;
+    float* mom_std = nullptr;
+    float mom_eps = 0.f;
+    int mom_G = 0;
 };
+hipError_t launch_splitk_epilogue_mom(const ConvParams& p, int epi, hipStream_t s);
+int moments_chunks(int G, int P);
 
 // Split-bf16 operand format ("bf16x3"): tensors keep their fp32 size and addressing, but every aligned group of
 // 32 channels (128 bytes) holds [32 x hi bf16 | 32 x lo bf16] with hi = bf16_rn(v), lo = bf16_rn(v - hi).

@@ -2,6 +2,7 @@
 // instance-norm apply, dense layers, latent sampler and the fused up-sample + leaky-relu + 4x4 conv head.
 // All are HBM-bound (or launch-bound) on MI355X: 16-byte coalesced accesses, 64-wide wave reductions.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace msr {
 
@@ -90,8 +91,87 @@ __global__ void __launch_bounds__(256) conv_smallcin_kernel(const SmallCinParams
     }
 }
 
+// Tiled form for Hout % 16 == 0: a workgroup owns a 16 x 16 output tile.  Its source window ((16 * ay + 2)^2 samples, already
+// resized / strided, zero outside) is staged through LDS once, so the inner loop has no bounds tests and no 64-bit address
+// arithmetic, and a thread's 18 tap weights serve 16 (COUT = 64) or 32 (COUT = 128) pixels instead of 4.  Same
+// multiplications and additions in the same order as conv_smallcin_kernel: bit-identical output.
+template <int COUT>
+__global__ void __launch_bounds__(256) conv_smallcin_tiled_kernel(const SmallCinParams p) {
+    constexpr int QUADS = COUT / 4, GRP = 256 / QUADS, PX = 4, WMAX = 2 * PX + 1, WW = 34;
+    __shared__ float2 win[WW * WW];
+    const int tiles = p.Hout >> 4;
+    int t = blockIdx.x;
+    const int tx0 = (t % tiles) << 4;
+    t /= tiles;
+    const int ty0 = (t % tiles) << 4;
+    const int b = t / tiles;
+    const int q = threadIdx.x % QUADS, pl = threadIdx.x / QUADS;
+    const int span = 15 * p.ay + 3;                       // window rows / columns the tile needs
+    const float* sb = p.src + (size_t)b * p.S * p.S * 2;
+    for (int i = threadIdx.x; i < span * span; i += 256) {
+        const int wy = i / span, wx = i - wy * span;
+        const int ty = ty0 * p.ay + wy + p.cy, tx = tx0 * p.ay + wx + p.cy;
+        const bool ok = ty >= 0 && ty < p.lim && tx >= 0 && tx < p.lim;
+        win[wy * WW + wx] = ok ? *reinterpret_cast<const float2*>(sb + ((size_t)(ty * p.f + p.o) * p.S + (tx * p.f + p.o)) * 2)
+                               : make_float2(0.f, 0.f);
+    }
+    float4 w[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) w[k] = *reinterpret_cast<const float4*>(p.w + k * COUT + q * 4);
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bias = *reinterpret_cast<const float4*>(p.bias + q * 4);
+    __syncthreads();
+    const int ncol = (PX - 1) * p.ay + 3;
+    for (int grp = pl; grp < 64; grp += GRP) {            // 64 groups of 4 adjacent pixels in the tile
+        const int gx = (grp & 3) * PX, gy = grp >> 2;
+        float2 v[3][WMAX];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int j = 0; j < WMAX; ++j)
+                v[kh][j] = j < ncol ? win[(gy * p.ay + kh) * WW + gx * p.ay + j] : make_float2(0.f, 0.f);
+        float* o = p.out + (size_t)p.out_off + (size_t)b * p.out_pb + (size_t)(ty0 + gy) * p.out_py + (size_t)(tx0 + gx) * p.out_px;
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+            float4 acc = bias;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float2 x = p.ay == 1 ? v[kh][(i + kw) < WMAX ? (i + kw) : 0] : v[kh][(2 * i + kw) < WMAX ? (2 * i + kw) : 0];
+                    const float4 w0 = w[(kh * 3 + kw) * 2], w1 = w[(kh * 3 + kw) * 2 + 1];
+                    acc.x += x.x * w0.x; acc.y += x.x * w0.y; acc.z += x.x * w0.z; acc.w += x.x * w0.w;
+                    acc.x += x.y * w1.x; acc.y += x.y * w1.y; acc.z += x.y * w1.z; acc.w += x.y * w1.w;
+                }
+            }
+            if (p.act == 1) {
+                acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+            } else if (p.act == 2) {
+                acc.x = acc.x >= 0.f ? acc.x : acc.x * p.slope; acc.y = acc.y >= 0.f ? acc.y : acc.y * p.slope;
+                acc.z = acc.z >= 0.f ? acc.z : acc.z * p.slope; acc.w = acc.w >= 0.f ? acc.w : acc.w * p.slope;
+            }
+            if (p.out_split == 4) {
+                msr_store_f16c4_dev(o + (size_t)i * p.out_px, q * 4, acc.x, acc.y, acc.z, acc.w);
+            } else if (p.out_split == 3) {
+                unsigned w8 = 0;
+                w8 = __builtin_amdgcn_cvt_pk_bf8_f32(acc.x, acc.y, w8, false);
+                w8 = __builtin_amdgcn_cvt_pk_bf8_f32(acc.z, acc.w, w8, true);
+                reinterpret_cast<unsigned*>(o + (size_t)i * p.out_px)[q] = w8;
+            } else if (p.out_split == 2) msr_store_split4_f16(o + (size_t)i * p.out_px, q * 4, acc.x, acc.y, acc.z, acc.w);
+            else if (p.out_split) msr_store_split4_dev(o + (size_t)i * p.out_px, q * 4, acc.x, acc.y, acc.z, acc.w);
+            else *reinterpret_cast<float4*>(o + (size_t)i * p.out_px + q * 4) = acc;
+        }
+    }
+}
+
 template <int COUT>
 static hipError_t launch_smallcin_t(const SmallCinParams& p, hipStream_t s) {
+    static const bool tiled_off = std::getenv("MSR_SMALLCIN_TILED") && std::atoi(std::getenv("MSR_SMALLCIN_TILED")) == 0;
+    // (a handful of tiles — the low-resolution embeddings — finish sooner one pixel group per thread)
+    if (p.Hout % 16 == 0 && p.B * (p.Hout / 16) * (p.Hout / 16) >= 64 && !tiled_off) {
+        conv_smallcin_tiled_kernel<COUT><<<p.B * (p.Hout / 16) * (p.Hout / 16), 256, 0, s>>>(p);
+        return hipGetLastError();
+    }
     constexpr int GRP = 256 / (COUT / 4);
     const int px = (p.Hout % 4 == 0) ? 4 : 1;
     const long total = (long)p.B * p.Hout * (p.Hout / px);
@@ -139,36 +219,37 @@ static int moments_chunk_pixels(int G, int P) {
     while (px > 8 && (long)G * ((P + px - 1) / px) < 256) px >>= 1;
     return px;
 }
+// ... and when 8-pixel chunks are still too few workgroups, the channels are cut as well (>= 64 quads per workgroup)
+static int moments_channel_blocks(int G, int P, int C) {
+    const long blocks = (long)G * ((P + moments_chunk_pixels(G, P) - 1) / moments_chunk_pixels(G, P));
+    int cb = 1;
+    while (blocks * cb < 256 && C / 4 / (cb * 2) >= 64 && (C / 4) % (cb * 2) == 0) cb *= 2;
+    return cb;
+}
 int moments_chunks(int G, int P) {
     const int px = moments_chunk_pixels(G, P);
     return (P + px - 1) / px;
 }
 
-__global__ void __launch_bounds__(256) moments_partial_kernel(const float* __restrict__ x, int P, int C,
-                                                              int chunk_px, double* __restrict__ partial) {
-    // partial layout: [G][chunks][C][2]
-    __shared__ double red[256 * 8];
-    const int quads = C / 4;
-    const int chunk = blockIdx.x, g = blockIdx.y, chunks = gridDim.x;
-    const int p0 = chunk * chunk_px;
-    const int p1 = min(P, p0 + chunk_px);
-    const float* xg = x + (size_t)g * P * C;
+// sums of one pixel chunk: the values come from `load(pixel, quad)` (a tensor in memory, or the split-K epilogue's freshly
+// combined output).  partial layout: [G][chunks][C][2]
+// A workgroup covers the channel quads [q_lo, q_lo + quads) of its pixel chunk (blockIdx.z cuts the channels when the
+// pixels alone do not give ~256 workgroups).
+template <typename Load>
+__device__ __forceinline__ void moments_chunk_sums(Load load, int p0, int p1, int C, int q_lo, int quads, int g, int chunk,
+                                                   int chunks, double* __restrict__ partial, double* red) {
     for (int qb = 0; qb < quads; qb += 256) {
         // layout A (quads >= 256): every thread one quad, all pixels.  layout B: several pixel slots per quad.
         const int tq = quads >= 256 ? 256 : quads;     // threads along channel quads
         const int slots = 256 / tq;                    // pixel slots
-        const int q = qb + threadIdx.x % tq;
+        const int q = q_lo + qb + threadIdx.x % tq;
         const int slot = threadIdx.x / tq;
         double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
-        if (q < quads) {
+        if (q < q_lo + quads) {
             // 4 independent 16-byte loads in flight per thread; short fp32 runs flushed into fp64 accumulators
-            const float* base = xg + q * 4;
             int pix = p0 + slot;
             for (; pix + 3 * slots < p1; pix += 4 * slots) {
-                const float4 v0 = *reinterpret_cast<const float4*>(base + (size_t)pix * C);
-                const float4 v1 = *reinterpret_cast<const float4*>(base + (size_t)(pix + slots) * C);
-                const float4 v2 = *reinterpret_cast<const float4*>(base + (size_t)(pix + 2 * slots) * C);
-                const float4 v3 = *reinterpret_cast<const float4*>(base + (size_t)(pix + 3 * slots) * C);
+                const float4 v0 = load(pix, q), v1 = load(pix + slots, q), v2 = load(pix + 2 * slots, q), v3 = load(pix + 3 * slots, q);
                 s[0] += (double)((v0.x + v1.x) + (v2.x + v3.x)); s[1] += (double)((v0.y + v1.y) + (v2.y + v3.y));
                 s[2] += (double)((v0.z + v1.z) + (v2.z + v3.z)); s[3] += (double)((v0.w + v1.w) + (v2.w + v3.w));
                 ss[0] += (double)((v0.x * v0.x + v1.x * v1.x) + (v2.x * v2.x + v3.x * v3.x));
@@ -177,7 +258,7 @@ __global__ void __launch_bounds__(256) moments_partial_kernel(const float* __res
                 ss[3] += (double)((v0.w * v0.w + v1.w * v1.w) + (v2.w * v2.w + v3.w * v3.w));
             }
             for (; pix < p1; pix += slots) {
-                const float4 v = *reinterpret_cast<const float4*>(base + (size_t)pix * C);
+                const float4 v = load(pix, q);
                 s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
                 ss[0] += (double)v.x * v.x; ss[1] += (double)v.y * v.y;
                 ss[2] += (double)v.z * v.z; ss[3] += (double)v.w * v.w;
@@ -186,7 +267,7 @@ __global__ void __launch_bounds__(256) moments_partial_kernel(const float* __res
 #pragma unroll
         for (int k = 0; k < 4; ++k) { red[threadIdx.x * 8 + k] = s[k]; red[threadIdx.x * 8 + 4 + k] = ss[k]; }
         __syncthreads();
-        if (slot == 0 && q < quads) {
+        if (slot == 0 && q < q_lo + quads) {
             for (int k = 0; k < 4; ++k) {
                 double a = 0, b = 0;
                 for (int sl = 0; sl < slots; ++sl) {
@@ -228,12 +309,81 @@ __global__ void __launch_bounds__(1024) moments_final_kernel(const double* __res
     }
 }
 
+__global__ void __launch_bounds__(256) moments_partial_kernel(const float* __restrict__ x, int P, int C, int chunk_px,
+                                                              double* __restrict__ partial) {
+    __shared__ double red[256 * 8];
+    const int chunk = blockIdx.x, g = blockIdx.y, chunks = gridDim.x;
+    const int p0 = chunk * chunk_px;
+    const int p1 = min(P, p0 + chunk_px);
+    const int quads = C / 4 / gridDim.z;
+    const float* xg = x + (size_t)g * P * C;
+    moments_chunk_sums([&](int pix, int q) { return *reinterpret_cast<const float4*>(xg + (size_t)pix * C + q * 4); },
+                       p0, p1, C, blockIdx.z * quads, quads, g, chunk, chunks, partial, red);
+}
+
 hipError_t launch_moments(const float* x, int G, int P, int C, float eps, double* partial, float* mean, float* stdv,
                           hipStream_t s) {
     if (C % 32) return hipErrorInvalidValue;
     const int chunks = moments_chunks(G, P);
-    moments_partial_kernel<<<dim3(chunks, G), 256, 0, s>>>(x, P, C, moments_chunk_pixels(G, P), partial);
+    moments_partial_kernel<<<dim3(chunks, G, moments_channel_blocks(G, P, C)), 256, 0, s>>>(x, P, C, moments_chunk_pixels(G, P),
+                                                                                          partial);
     moments_final_kernel<<<G * (C / 32), 1024, 0, s>>>(partial, G, chunks, C, P, eps, mean, stdv);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// splitk_epilogue_mom: the split-K epilogue (EPI_BIAS / EPI_RES) of a conv whose output feeds a normalisation, with that
+// normalisation's moments: a workgroup combines the K ranges of one pixel chunk, writes the output and adds it up on the
+// way — the tensor is not read again and the moments' first launch disappears (moments_final_kernel follows).  Same sums,
+// same order as moments_partial_kernel over the finished tensor.  (A single launch that lets the last workgroup finish the
+// sums was tried: the device-scope release every workgroup needs before its ticket writes back the XCD's L2 — 8 separate
+// L2s on this part — and cost 20-120 us per layer, profiles/r03_early_phase.txt.)
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ void __launch_bounds__(256) splitk_epilogue_mom_kernel(const ConvParams p, int chunk_px) {
+    __shared__ double red[256 * 8];
+    const int chunk = blockIdx.x, g = blockIdx.y, chunks = gridDim.x;
+    const int P = (p.mom_G > 1 ? 1 : p.B) * p.Hout * p.Wout;        // pixels per group: one sample, or the whole batch
+    const int p0 = chunk * chunk_px;
+    const int p1 = min(P, p0 + chunk_px);
+    const size_t pstride = (size_t)p.B * p.Hout * p.Wout * p.N;
+    auto load = [&](int pl, int q) {
+        const long pix = (long)g * P + pl;
+        const int x = (int)(pix % p.Wout);
+        const int y = (int)((pix / p.Wout) % p.Hout);
+        const int b = (int)(pix / ((long)p.Wout * p.Hout));
+        const int c = q * 4;
+        const float* pp = p.partial + (size_t)pix * p.N + c;
+        float4 a = *reinterpret_cast<const float4*>(pp);
+        for (int k = 1; k < p.ksplit; ++k) {
+            const float4 t = *reinterpret_cast<const float4*>(pp + k * pstride);
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+        const float4 b0v = *reinterpret_cast<const float4*>(p.bias + c);
+        float4 v = make_float4(a.x + b0v.x, a.y + b0v.y, a.z + b0v.z, a.w + b0v.w);
+        if constexpr (EPI == EPI_RES) {
+            const float4 xv = *reinterpret_cast<const float4*>(p.aux + (size_t)b * p.aux_pb +
+                                                               (size_t)(y >> p.aux_shift) * p.aux_py +
+                                                               (size_t)(x >> p.aux_shift) * p.aux_px + c);
+            v.x += xv.x; v.y += xv.y; v.z += xv.z; v.w += xv.w;
+        }
+        float* opix = p.out + (size_t)p.out_off + (size_t)b * p.out_pb + (size_t)y * p.out_py + (size_t)x * p.out_px;
+        *reinterpret_cast<float4*>(opix + c) = v;
+        return v;
+    };
+    const int quads = p.N / 4 / gridDim.z;
+    moments_chunk_sums(load, p0, p1, p.N, blockIdx.z * quads, quads, g, chunk, chunks, p.mom_partial, red);
+}
+
+hipError_t launch_splitk_epilogue_mom(const ConvParams& p, int epi, hipStream_t s) {
+    const int G = p.mom_G > 1 ? p.B : 1;
+    if ((epi != EPI_BIAS && epi != EPI_RES) || p.N % 32 || !p.mom_partial) return hipErrorInvalidValue;
+    const int P = (G > 1 ? 1 : p.B) * p.Hout * p.Wout;
+    const int chunks = moments_chunks(G, P);
+    const dim3 grid(chunks, G, moments_channel_blocks(G, P, p.N));
+    if (epi == EPI_BIAS) splitk_epilogue_mom_kernel<EPI_BIAS><<<grid, 256, 0, s>>>(p, moments_chunk_pixels(G, P));
+    else splitk_epilogue_mom_kernel<EPI_RES><<<grid, 256, 0, s>>>(p, moments_chunk_pixels(G, P));
+    moments_final_kernel<<<G * (p.N / 32), 1024, 0, s>>>(p.mom_partial, G, chunks, p.N, P, p.mom_eps, p.mom_mean, p.mom_std);
     return hipGetLastError();
 }
 
@@ -320,9 +470,7 @@ __global__ void __launch_bounds__(128) dense_partial_kernel(const float* __restr
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* wp = W + (size_t)k0 * N + col;
-#pragma unroll 8
-    for (int k = 0; k < kn; ++k) {
-        const float4 w = *reinterpret_cast<const float4*>(wp + (size_t)k * N);
+    auto fma_row = [&](int k, const float4 w) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const float xr = xs[k * NB + b];
@@ -330,7 +478,29 @@ __global__ void __launch_bounds__(128) dense_partial_kernel(const float* __restr
             a.x = fmaf(xr, w.x, a.x); a.y = fmaf(xr, w.y, a.y);
             a.z = fmaf(xr, w.z, a.z); a.w = fmaf(xr, w.w, a.w);
         }
+    };
+    // Two register buffers of 8 weight rows: the next 8 rows are requested before the current 8 are consumed, so a wave
+    // always has 8-16 KiB on its way (a single unrolled group left the memory pipe idle while it multiplied: 268 MB of
+    // encoder-head weights streamed at 3 TB/s at B = 8).  Same additions in the same order.
+    float4 wa[8], wb[8];
+    int k = 0;
+    if (kn >= 16) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wa[u] = *reinterpret_cast<const float4*>(wp + (size_t)u * N);
+        for (; k + 16 <= kn; k += 16) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wb[u] = *reinterpret_cast<const float4*>(wp + (size_t)(k + 8 + u) * N);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) fma_row(k + u, wa[u]);
+            if (k + 32 <= kn) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) wa[u] = *reinterpret_cast<const float4*>(wp + (size_t)(k + 16 + u) * N);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) fma_row(k + 8 + u, wb[u]);
+        }
     }
+    for (; k < kn; ++k) fma_row(k, *reinterpret_cast<const float4*>(wp + (size_t)k * N));
 #pragma unroll
     for (int b = 0; b < NB; ++b)
         if (b < B) *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.y * B + b) * N + col) = acc[b];
