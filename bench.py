@@ -59,20 +59,25 @@ WORKLOADS = {
 }
 # MI355X_MICROARCH.md: dense MFMA peaks.  For bf16x3 every algorithmic product costs three bf16 MFMA products, so
 # the algorithmic ceiling is a third of the bf16 peak; `achieved` stays ALGORITHMIC FLOP/s in every mode.
-PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16x3_gbf16": 2500.0, "fp8": 5000.0, "f16c": 2500.0}
+PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16x3_gbf16": 2500.0, "fp8": 5000.0, "f16c": 2500.0, "f16": 2500.0}
 # MFMA products per algorithmic product; the opt-in mode runs 2 in the gamma|beta convs (half of the FLOPs), 3 elsewhere
 # f16c since round 3: the gamma|beta convs (half of the FLOPs) run conv_gb_resident with fp6 cross terms (1.5), the main convs 2
-MFMA_PER_PRODUCT = {"fp32": 1, "bf16x3": 3, "bf16x3_gbf16": 2.5, "fp8": 1, "f16c": 1.75}
+# f16: one product in conv_gb_resident / conv_igemm_f16c_sw (~95 % of the FLOPs), f16c / bf16x3 forms in the rest
+MFMA_PER_PRODUCT = {"fp32": 1, "bf16x3": 3, "bf16x3_gbf16": 2.5, "fp8": 1, "f16c": 1.75, "f16": 1.1}
 # the kernels behind the conv family of each mode (the library's profiler names the family by its base mode)
 KERNELS = {"fp32": "conv_igemm<..., PREC_F32> (v_mfma_f32_32x32x2_f32)",
            "bf16x3": "conv_igemm_bf16x3_pp (ping-pong, 3-term split-bf16) + small-tile split-K forms",
            "bf16x3_gbf16": "conv_igemm_bf16x3_pp (gamma|beta convs 2-term fp16, main convs 3-term split-bf16)",
            "f16c": "conv_gb_resident (SPADE layers: embedding + gamma|beta conv + epilogue, f16 + fp6 cross terms) + "
                    "conv_igemm_f16c_sw (main convs, f16 + fp8 cross terms); bf16x3 forms on the layers that do not fill the chip",
+           "f16": "conv_gb_resident<NOX> + conv_igemm_f16c_sw<NOX> (one v_mfma_f32_16x16x32_f16 product per element, cross terms "
+                  "left out); f16c / bf16x3 forms on the layers that do not fill the chip",
            "fp8": "conv_igemm_bf16x3_pp<PP_FP8> (block-scaled v_mfma_scale_f32_16x16x128_f8f6f4, fp8 x fp8); bf16x3 forms elsewhere"}
 DTYPE = {"fp32": "f32", "bf16x3": "bf16x3 (f32 in/out/accumulate)",
          "bf16x3_gbf16": "bf16x3, gamma|beta convs f16x2 (opt-in; f32 in/out/accumulate; 2-5e-4 rel L-inf, inside the 1e-3 bar)",
          "f16c": "f16 main term + fp8 / fp6 cross terms in the chip-filling convs, bf16x3 elsewhere (f32 in/out/accumulate; parity mode)",
+         "f16": "one fp16 product per element in the two big kernels (DECLARED TOLERANCE, the usable reading of BASELINE configs[4]; "
+                "f32 in/out/accumulate; error stated in tests/test_gpu_baseline_configs.py)",
          "fp8": "fp8 e4m3 weights x bf8 e5m2 activations in the chip-filling convs, bf16x3 elsewhere (DECLARED NON-PARITY: "
                 "BASELINE configs[4]; f32 in/out/accumulate; error stated in tests/test_gpu_baseline_configs.py)"}
 
@@ -418,7 +423,7 @@ def main():
                        with_b1=solo and not args.no_also)
     if solo and not args.no_also:
         also = {}
-        for wl, prec in (("spade512", "fp32"), ("spade512", "bf16x3"), ("spade512", "bf16x3_gbf16"), ("spade512", "fp8"),
+        for wl, prec in (("spade512", "fp32"), ("spade512", "bf16x3"), ("spade512", "bf16x3_gbf16"), ("spade512", "fp8"), ("spade512", "f16"),
                          ("spade256", "f16c"), ("spade256", "bf16x3"), ("spade256", "fp32")):
             if (wl, prec) == (args.workload, args.precision):
                 continue

@@ -83,6 +83,14 @@ typedef struct {
  *                     of three, per-product error ~2^-15, 3-5e-5 relative L-inf end to end — a parity mode
  *                     (tests/test_gpu_baseline_configs.py). */
 #define MSR_FLAG_F16C 8
+/*   MSR_FLAG_BF16X3 | MSR_FLAG_F16C | MSR_FLAG_F16_MAIN   declared-tolerance fast mode ("f16", round 3): the F16C data
+ *                     path with the cross terms left out of the two kernels that carry ~95 % of the FLOPs (conv_gb_resident,
+ *                     conv_igemm_f16c_sw): ONE fp16 product per element on v_mfma_f32_16x16x32_f16, fp32 accumulation,
+ *                     per-product error 2^-11.  Tensors, weights and every other layer are exactly F16C's.  It is the usable
+ *                     reading of BASELINE.json configs[4] ("fp16 ... conv"): the measured end-to-end error is stated in
+ *                     tests/test_gpu_baseline_configs.py::test_f16_mode_declared_tolerance (bound 3e-2 relative L-inf; it is
+ *                     NOT inside north_star's 1e-3 and never the default). */
+#define MSR_FLAG_F16_MAIN 16
 
 typedef struct msr_handle msr_handle;
 

@@ -20,7 +20,8 @@ VARIANT_IDS = {"gaugan": 0, "gaugan_no_kl": 1, "cnn": 2, "pix2pix": 3}
 # msr_config.flags: MSR_FLAG_BF16X3 = 1, MSR_FLAG_GB_F16X2 = 2 (opt-in 2-term fp16 products in the gamma|beta convs)
 # MSR_FLAG_FP8 = 4: declared non-parity mode (fp8 weights x bf8 activations in the chip-filling convs)
 # MSR_FLAG_F16C = 8: fp16 main term + fp8 cross terms in the chip-filling convs (parity-grade, 2 MFMA-equivalents per product)
-PRECISION_FLAGS = {"fp32": 0, "bf16x3": 1, "bf16x3_gbf16": 3, "fp8": 5, "f16c": 9}
+# MSR_FLAG_F16_MAIN = 16 (with F16C): the cross terms left out of the stream / resident kernels ("f16": declared tolerance)
+PRECISION_FLAGS = {"fp32": 0, "bf16x3": 1, "bf16x3_gbf16": 3, "fp8": 5, "f16c": 9, "f16": 25}
 
 
 class MsrConfig(C.Structure):

@@ -64,6 +64,7 @@ struct msr_handle {
     bool gb_f16x2 = false;                       // MSR_FLAG_GB_F16X2: 2-term fp16 products in the gamma|beta convs
     bool fp8 = false;                            // MSR_FLAG_FP8: declared non-parity mode (fp8 weights x bf8 activations)
     bool f16c = false;                           // MSR_FLAG_F16C: fp16 main term + fp8 cross terms in the chip-filling convs
+    bool f16m = false;                           // MSR_FLAG_F16_MAIN: F16C without the cross terms in the stream / resident kernels
     std::string err;
     std::vector<WeightSpec> specs;
     std::map<std::string, int> spec_index;
@@ -649,6 +650,9 @@ int msr_create(const msr_config* cfg, msr_handle** out) {
     if ((cfg->flags & MSR_FLAG_F16C) && (!(cfg->flags & MSR_FLAG_BF16X3) || (cfg->flags & (MSR_FLAG_GB_F16X2 | MSR_FLAG_FP8))))
         return fail(nullptr, MSR_ERR_INVALID, "MSR_FLAG_F16C goes with MSR_FLAG_BF16X3 alone (the layers it does not cover run bf16x3)");
     h->f16c = (cfg->flags & MSR_FLAG_F16C) && cfg->variant != MSR_PIX2PIX;
+    if ((cfg->flags & MSR_FLAG_F16_MAIN) && !(cfg->flags & MSR_FLAG_F16C))
+        return fail(nullptr, MSR_ERR_INVALID, "MSR_FLAG_F16_MAIN modifies MSR_FLAG_F16C");
+    h->f16m = h->f16c && (cfg->flags & MSR_FLAG_F16_MAIN);
     if (cfg->variant == MSR_PIX2PIX) { h->prec = PREC_F32; h->gb_f16x2 = false; }   // the parity config runs on the fp32 MFMA
     build_specs(h.get());
     *out = h.release();
@@ -1078,6 +1082,7 @@ int plan_spade(msr_handle* h) {
                 q.out = ab.base; q.out_px = ab.C; q.out_py = ab.py(); q.out_pb = ab.pb(); q.out_off = ab.interior();
                 q.out_split = 4; q.slope = 0.2f;
                 q.B = B; q.r = r; q.N = 2 * C;
+                q.no_cross = h->f16m ? 1 : 0;
                 g.flops = 2.0 * B * r * r * 128.0 * (2 * C) * 9 + 2.0 * B * r * r * 18.0 * 128;
                 h->ops.push_back(g);
             } else {
@@ -1153,6 +1158,7 @@ int plan_spade(msr_handle* h) {
                 cv.tile = TILE_256x128_PP;
                 cv.conv.ksplit = pp_ksplit(B, r, f, 1, C);
                 cv.conv.wt_frag = 0;
+                cv.conv.no_cross = h->f16m ? 1 : 0;           // honoured by conv_igemm_f16c_sw (the long-K main convs)
             }
             set_out_dense(cv.conv, y, r, f);
             if (epi == EPI_RES) set_aux_dense(cv.conv, res, res_r, f, res_shift);
@@ -1215,7 +1221,7 @@ int plan_spade(msr_handle* h) {
             if (!op.on_aux) op.wait = (int)k == first_wait ? h->ops[last_aux].done : nullptr;
         }
     }
-    mom_doubles = std::max<size_t>(mom_doubles, (size_t)32 * 3 * 1024);   // also the slab-group scratch
+    mom_doubles = std::max<size_t>(mom_doubles, (size_t)128 * 3 * 1024);  // also the slab-group scratch
     HIPCHK(h, hipMalloc(&h->mom_partial, std::max<size_t>(mom_doubles, 16) * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->dense_partial, std::max<size_t>(dense_part, 16) * sizeof(float)));
     h->total_bytes += mom_doubles * sizeof(double) + dense_part * sizeof(float);

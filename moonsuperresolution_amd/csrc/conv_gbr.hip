@@ -75,6 +75,10 @@ struct GbrGeom {
 #define GB_PDC 3
 #endif
 
+// NOX = true (GbrParams.no_cross, the "f16" mode): the fp6 cross terms are left out of the sweep — one fp16 product per
+// element (per-product error 2^-11; declared tolerance, include/moonsr.h MSR_FLAG_F16_MAIN).  Phase 1 and the weight
+// stream are unchanged; the cross pieces are not read.
+template <bool NOX>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 conv_gb_resident(const GbrParams p, const GbrGeom g) {
     constexpr int PH = GB_PH, HW = 18, HP = 324;
@@ -361,8 +365,10 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
     {                                                                                            \
         dstE[j] = GB_BUFLD(wv[j], GB_WSOFF(P));                                                  \
         dstO[j] = GB_BUFLD(wv[j] + 1024, GB_WSOFF(P));                                           \
-        dxE[j] = GB_BUFLD(wv[j] + 2048, GB_WSOFF(P));                                            \
-        dxO[j] = GB_BUFLD(wv[j] + 3072, GB_WSOFF(P));                                            \
+        if constexpr (!NOX) {                                                                    \
+            dxE[j] = GB_BUFLD(wv[j] + 2048, GB_WSOFF(P));                                        \
+            dxO[j] = GB_BUFLD(wv[j] + 3072, GB_WSOFF(P));                                        \
+        }                                                                                        \
     }
 #define GB_F16(v) __builtin_bit_cast(f16x8, v)
 #define GB_CAT8(lo, hi) __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)
@@ -386,10 +392,12 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
         constexpr int T = 2 * (U) + 1;                                                           \
         const char* const xpa_ = GB_XPA(CB, T - 1);                                              \
         const char* const xpb_ = GB_XPB(CB, T - 1);                                              \
-        xsc = *reinterpret_cast<const i32x4*>(GB_SP(CB, T - 1));                                 \
+        if constexpr (!NOX) xsc = *reinterpret_cast<const i32x4*>(GB_SP(CB, T - 1));             \
         _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                         \
             if (i + PD < 16) GB_RD_F(fb[(i + PD) & 15], CB, T, (i + PD) & 15);                   \
-            if (i >= 16 - PDC) GB_RD_X((i + PDC) & 15, xpa_, xpb_, (i + PDC) & 15)               \
+            if constexpr (NOX) {    /* no phase C: its requests of the next pair's fa move here */ \
+                if (i >= 16 - PD) GB_RD_F(fa[(i + PD) & 15], CB, T + 1, (i + PD) & 15);          \
+            } else if (i >= 16 - PDC) GB_RD_X((i + PDC) & 15, xpa_, xpb_, (i + PDC) & 15)        \
             acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(GB_F16(bO[0]), GB_F16(fb[i]), acc[i][0], 0, 0, 0); \
             acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(GB_F16(bO[1]), GB_F16(fb[i]), acc[i][1], 0, 0, 0); \
             __builtin_amdgcn_sched_barrier(0);                                                   \
@@ -413,10 +421,12 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
         const i32x8 wq0_ = GB_CAT8(xE[0], xO[0]), wq1_ = GB_CAT8(xE[1], xO[1]);                  \
         const char* const xpa_ = GB_XPA(CB, T);                                                  \
         const char* const xpb_ = GB_XPB(CB, T);                                                  \
+        if constexpr (!NOX) {                                                                    \
         GB_C_STEP(CB, T, 0) GB_C_STEP(CB, T, 1) GB_C_STEP(CB, T, 2) GB_C_STEP(CB, T, 3)          \
         GB_C_STEP(CB, T, 4) GB_C_STEP(CB, T, 5) GB_C_STEP(CB, T, 6) GB_C_STEP(CB, T, 7)          \
         GB_C_STEP(CB, T, 8) GB_C_STEP(CB, T, 9) GB_C_STEP(CB, T, 10) GB_C_STEP(CB, T, 11)        \
         GB_C_STEP(CB, T, 12) GB_C_STEP(CB, T, 13) GB_C_STEP(CB, T, 14) GB_C_STEP(CB, T, 15)      \
+        }                                                                                        \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) { bE[j] = nbE[j]; bO[j] = nbO[j]; xE[j] = nxE[j]; xO[j] = nxO[j]; } \
     }
 #define GB_PAIR(CB, U) GB_PHASE_E(CB, U) GB_PHASE_O(CB, U) GB_PHASE_C(CB, U)
@@ -548,7 +558,10 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
 }
 
 hipError_t conv_gbr_init() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gb_resident), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gb_resident<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GB_LDS);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gb_resident<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)GB_LDS);
 }
 
@@ -584,7 +597,8 @@ hipError_t launch_conv_gbr(const GbrParams& p, int ranges, hipStream_t s) {
         if (n_cu < 8) n_cu = 8;
     }
     const int grid = g.items < n_cu ? ((g.items + 7) & ~7) : n_cu;
-    conv_gb_resident<<<grid, 256, GB_LDS, s>>>(p, g);
+    if (p.no_cross) conv_gb_resident<true><<<grid, 256, GB_LDS, s>>>(p, g);
+    else conv_gb_resident<false><<<grid, 256, GB_LDS, s>>>(p, g);
     return hipGetLastError();
 }
 

@@ -193,7 +193,10 @@ __device__ __forceinline__ void sw_epilogue(const ConvParams& p, const SwGeom& g
 // per K = 128 MFMA.  A lane then reads ONE 32-byte half of ONE tap's chunk row (the even tap's for lane groups 0 / 1, the odd
 // tap's for 2 / 3; first / second half for even / odd groups): the same two 16-byte loads as before, the operand in the
 // first six registers, the block scale in byte 0 of the seventh.
-template <int EPI, bool F6 = false>
+// NOX = true ("f16" mode, ConvParams.no_cross): the cross terms are left out — one fp16 product per element, per-product
+// error 2^-11 instead of ~2^-15 (a declared-tolerance mode, see include/moonsr.h MSR_FLAG_F16_MAIN); the tensors keep the
+// f16c image, the cross pieces are simply not read.
+template <int EPI, bool F6 = false, bool NOX = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 conv_igemm_f16c_sw(const ConvParams p, const SwGeom g) {
     constexpr int HW = SW_HW, HP = SW_HP, BKP = SW_BKP, HPB = SW_HPB;
@@ -284,7 +287,8 @@ conv_igemm_f16c_sw(const ConvParams p, const SwGeom g) {
     {                                                                                            \
         dstE[j] = SW_BUFLD(rs_wt, b_voff[j], SW_WSOFF(T));                                       \
         dstO[j] = SW_BUFLD(rs_wt, b_voff[j], SW_WSOFF((T) + 1));                                 \
-        if constexpr (F6) {                                                                      \
+        if constexpr (NOX) {                                                                     \
+        } else if constexpr (F6) {                                                                      \
             /* both 16-byte halves of the lane's piece, from the even tap's row (lane groups 0, 1) or the odd tap's (2, 3); \
                the scalar offset is the smaller of the two taps' (the other one's excess rides in the lane offset) */ \
             const unsigned lo_ = min(SW_WSOFF(T), SW_WSOFF((T) + 1));                            \
@@ -368,7 +372,10 @@ conv_igemm_f16c_sw(const ConvParams p, const SwGeom g) {
         const float* const xp_ = SW_XP(T - 1);                                                   \
         _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                         \
             if (i + PD < 16) SW_RD_F(fb[(i + PD) & 15], T, (i + PD) & 15);                       \
-            if (i >= 16 - PDC) {                                                                 \
+            if constexpr (NOX) {    /* no phase C: its barrier and its requests of the next pair's fa move here */ \
+                if (T + 1 == 18 && i == 16 - PD) SW_BARRIER()                                    \
+                if (i >= 16 - PD) SW_RD_F(fa[(i + PD) & 15], T + 1, (i + PD) & 15);              \
+            } else if (i >= 16 - PDC) {                                                          \
                 if constexpr (F6) {                                                              \
                     SW_RD_X6(ce[(i + PDC) & 15], co[(i + PDC) & 15], xp_, (i + PDC) & 15)        \
                 } else {                                                                         \
@@ -389,6 +396,7 @@ conv_igemm_f16c_sw(const ConvParams p, const SwGeom g) {
         SW_STAMP(2)                                                                              \
         const i32x8 wq0_ = SW_CAT8(xE[0], xO[0]), wq1_ = SW_CAT8(xE[1], xO[1]);                  \
         const float* const xp_ = SW_XP(T);                                                       \
+        if constexpr (!NOX) {                                                                    \
         _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                         \
             if (T + 2 == 18 && i == 16 - PD) SW_BARRIER()                                        \
             if (i + PDC < 16) {                                                                  \
@@ -409,6 +417,7 @@ conv_igemm_f16c_sw(const ConvParams p, const SwGeom g) {
                 acc[i][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wq1_, aq_, acc[i][1], 0, 0, 0, wsc[1], 0, asc); \
             }                                                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                   \
+        }                                                                                        \
         }                                                                                        \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) { bE[j] = nbE[j]; bO[j] = nbO[j]; xE[j] = nxE[j]; xO[j] = nxO[j]; } \
     }
@@ -545,6 +554,10 @@ hipError_t conv_sw_init() {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)SW_LDS)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f16c_sw<EPI_RES, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)SW_LDS)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f16c_sw<EPI_BIAS, false, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)SW_LDS)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f16c_sw<EPI_RES, false, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)SW_LDS)) != hipSuccess) return e;
     return hipSuccess;
 }
 
@@ -576,6 +589,12 @@ hipError_t launch_conv_f16c_sw(const ConvParams& p, int epi, hipStream_t s) {
     if (f6) {
         if (epi == EPI_BIAS) conv_igemm_f16c_sw<EPI_BIAS, true><<<grid, 256, SW_LDS, s>>>(p, g);
         else conv_igemm_f16c_sw<EPI_RES, true><<<grid, 256, SW_LDS, s>>>(p, g);
+        return hipGetLastError();
+    }
+    if (p.no_cross) {
+        if (epi == EPI_BIAS) conv_igemm_f16c_sw<EPI_BIAS, false, true><<<grid, 256, SW_LDS, s>>>(p, g);
+        else if (epi == EPI_RES) conv_igemm_f16c_sw<EPI_RES, false, true><<<grid, 256, SW_LDS, s>>>(p, g);
+        else return hipErrorInvalidValue;          // the gamma|beta convs of the mode run conv_gb_resident
         return hipGetLastError();
     }
     switch (epi) {

@@ -74,6 +74,7 @@ struct ConvParams {
     float* mom_std = nullptr;
     float mom_eps = 0.f;
     int mom_G = 0;
+    int no_cross = 0;             // PREC_F16C on conv_igemm_f16c_sw only: 1 = leave the cross terms out ("f16" mode)
 };
 hipError_t launch_splitk_epilogue_mom(const ConvParams& p, int epi, hipStream_t s);
 int moments_chunks(int G, int P);
@@ -301,6 +302,7 @@ struct GbrParams {
     int out_split;          // 4: the f16c chunk image (PREC_F16C consumer)
     float slope;
     int B, r, N;
+    int no_cross = 0;             // 1 = leave the fp6 cross terms out ("f16" mode)
 };
 hipError_t conv_gbr_init();
 // > 0: the layer runs conv_gb_resident with the channel blocks of a pixel tile cut into that many work items; 0: not a layer

@@ -40,7 +40,9 @@ class Generator:
             opt-in faster mode: bf16x3, with 2-term fp16 products (weight rounded to one fp16) in the SPADE
             gamma|beta convs — 2-5e-4 end to end, inside the bar with a small margin.  "fp8" is the declared
             NON-parity mode of BASELINE configs[4] (fp8 e4m3 weights x bf8 e5m2 activations on the block-scaled
-            fp8 MFMA in the chip-filling convs): it does not meet the 1e-3 bar.  Inputs, outputs, weights and
+            fp8 MFMA in the chip-filling convs): it does not meet the 1e-3 bar.  "f16" is the declared-tolerance fast
+            mode of round 3: the f16c data path with the cross terms left out of the two big kernels (one fp16 product
+            per element; error stated in tests/test_gpu_baseline_configs.py).  Inputs, outputs, weights and
             every non-conv op (moments, normalisation, epilogues, dense, head) are fp32 in every mode.
     """
 

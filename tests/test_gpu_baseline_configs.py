@@ -204,6 +204,31 @@ def test_last_batch_of_a_tile_one_patch_and_seven_zero_patches(hip_lib, precisio
     assert np.isfinite(y).all() and err <= TOL and err_real <= TOL, (err, err_real)
 
 
+F16_TOL = 3e-3     # declared (VERDICT r2 item 3 asked for <= 3e-2 for a usable configs[4] mode).  Measured 8.9e-4 / 8.0e-4
+                   # relative L-inf, 6.3e-4 rms at (256,16) / (512,8): inside north_star's 1e-3 at these shapes, but with a 1.1x
+                   # margin only — which is why "f16" is a declared-tolerance mode and "f16c" (4e-5) stays the default
+
+
+@pytest.mark.parametrize("S,B", [(256, 16), (512, 8)])
+def test_f16_mode_declared_tolerance(hip_lib, S, B):
+    """precision="f16" (MSR_FLAG_F16_MAIN): the f16c data path with the cross terms left out of conv_gb_resident and
+    conv_igemm_f16c_sw — ONE fp16 product per element.  A single fp8 product cannot meet 3e-2 on this network whatever the
+    scaling recipe (profiles/r03_fp8_mode_emulation.txt: 0.09-0.26), a single fp16 product can: the relative L-infinity
+    against the oracle is measured, recorded and bounded by F16_TOL.  Not a parity mode (north_star: 1e-3)."""
+    from moonsuperresolution_amd import Generator
+    x, w, eps, ref, cap, oracle_dtype = _oracle(S, B)
+    gen = Generator(S, B, variant="gaugan", weights=w, eps=eps, precision="f16")
+    y = gen(x, training=False)
+    err = rel_linf(y, ref)
+    rms = float(np.sqrt(np.mean((np.asarray(y, np.float64) - ref) ** 2)) / np.sqrt(np.mean(ref ** 2)))
+    _record(S=S, B=B, precision="f16", oracle=oracle_dtype, rel_linf_output=err, rel_rms_output=rms,
+            note="declared-tolerance mode (one fp16 product per element)")
+    gen.close()
+    del gen
+    torch.cuda.empty_cache()
+    assert np.isfinite(y).all() and err <= F16_TOL, err
+
+
 FP8_TOL = 0.25     # declared, NON-parity (measured 0.16 relative L-inf, 0.13 relative rms at both BASELINE sizes)
 
 
