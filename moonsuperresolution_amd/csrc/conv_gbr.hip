@@ -81,6 +81,7 @@ struct GbrGeom {
 template <bool NOX>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 conv_gb_resident(const GbrParams p, const GbrGeom g) {
+    MSR_SATURATING_CONVERSIONS();
     constexpr int PH = GB_PH, HW = 18, HP = 324;
     constexpr int PD = GB_PD, PDC = GB_PDC;
     extern __shared__ __attribute__((aligned(16))) char smem[];

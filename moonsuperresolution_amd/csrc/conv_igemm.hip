@@ -536,6 +536,7 @@ __device__ __forceinline__ void halo16_epilogue(const ConvParams& p, const TileG
 template <int WM, int WN, int MT, int NT, int BKC, int EPI, int PREC>
 __global__ void __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2, BKC == 16 ? 3 : 2)))
 conv_igemm(const ConvParams p, const TileGeom g) {
+    MSR_SATURATING_CONVERSIONS();
     static_assert(PREC == PREC_F32 || BKC == 32, "the split-bf16 path uses the 32-channel K-step");
     constexpr int NTHR = WM * WN * 64;
     constexpr int BM = WM * MT * 32;
@@ -780,6 +781,7 @@ conv_igemm(const ConvParams p, const TileGeom g) {
 template <int WM, int WN, int MT, int NT, int EPI>
 __global__ void __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv_igemm_bf16x3(const ConvParams p, const TileGeom g) {
+    MSR_SATURATING_CONVERSIONS();
     static_assert(NT == 2, "B register sets are written for two n-tiles per wave");
     constexpr int NTHR = WM * WN * 64;
     constexpr int BM = WM * MT * 32;
@@ -971,6 +973,7 @@ conv_igemm_bf16x3(const ConvParams p, const TileGeom g) {
 template <int EPI, int SH>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv_igemm_bf16x3_halo(const ConvParams p, const TileGeom g) {
+    MSR_SATURATING_CONVERSIONS();
     constexpr int WM = 2, WN = 2, MT = 2, NT = 2;
     constexpr int NTHR = 256, BM = 128, BN = 128, BKC = 32, BKP = SH ? 40 : 36;
     constexpr int TH = 8, TW = 16, HH = TH + 2, HW = TW + 2, HP = HH * HW;   // 180 halo pixels
@@ -1244,6 +1247,7 @@ enum PpMode : int { PP_BF16X3 = 0, PP_F16X2 = 1, PP_FP8 = 2, PP_F16C = 3 };
 template <int EPI, int MODE, bool ONE = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
+    MSR_SATURATING_CONVERSIONS();
     constexpr bool F16X2 = MODE == PP_F16X2;
     constexpr int NTHR = 512, BN = 128, BKC = 32, BKP = 40;
     constexpr int TH = 16, TW = 16, HW = TW + 2, HP = (TH + 2) * HW;          // 324 halo pixels
@@ -1662,6 +1666,7 @@ conv_igemm_bf16x3_pp(const ConvParams p, const TileGeom g) {
 // ------------------------------------------------------------------------------------------------------
 template <int EPI>
 __global__ void __launch_bounds__(256) splitk_epilogue_kernel(const ConvParams p) {
+    MSR_SATURATING_CONVERSIONS();
     const int Cout = EPI == EPI_SPADE ? p.N / 2 : p.N;
     const int quads = Cout / 4;
     const long M = (long)p.B * p.Hout * p.Wout;

@@ -199,6 +199,7 @@ __device__ __forceinline__ void sw_epilogue(const ConvParams& p, const SwGeom& g
 template <int EPI, bool F6 = false, bool NOX = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 conv_igemm_f16c_sw(const ConvParams p, const SwGeom g) {
+    MSR_SATURATING_CONVERSIONS();
     constexpr int HW = SW_HW, HP = SW_HP, BKP = SW_BKP, HPB = SW_HPB;
     constexpr int NTHR = 256, BKC = 32;
     constexpr int H_ITEMS = (HP * 8 + NTHR - 1) / NTHR;                // 11 16-byte items per thread and chunk

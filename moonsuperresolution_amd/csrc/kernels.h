@@ -230,6 +230,13 @@ __device__ inline int msr_block_e8m0_dev(float amax) {
     return eb < 27 ? 27 : (eb > 247 ? 247 : eb);
 }
 
+// First statement of every kernel that converts activations to fp16 / fp8 pieces: MODE.FP16_OVFL = 1.  By default the fp8
+// converters return NaN beyond the format's range (v_cvt_pk_fp8_f32(480) = 0x7f) and v_cvt_f16_f32 returns infinity; with the
+// bit set they saturate (448 / 57344 / 65504; tools/gpu_diag_fp8_ovfl.hip, profiles/r03_fp8_conversion_overflow.txt).  A
+// saturated piece costs accuracy (tests/test_gpu_conv_kernel.py::test_f16c_saturation_regimes); a NaN piece poisons the tile.
+// MODE is per-wave state, initialised at wave launch: nothing outlives the kernel.
+#define MSR_SATURATING_CONVERSIONS() asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1")
+
 // Device: 4 consecutive channels c..c+3 (c % 4 == 0) of one pixel into the pixel's f16c chunk image (PREC_F16C above).
 __device__ inline void msr_store_f16c4_dev(float* pixel, int c, float v0, float v1, float v2, float v3) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));

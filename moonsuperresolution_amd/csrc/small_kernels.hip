@@ -22,6 +22,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ------------------------------------------------------------------------------------------------
 template <int COUT, int PX>   // PX adjacent output pixels per thread share their 3 x (PX+2) source window
 __global__ void __launch_bounds__(256) conv_smallcin_kernel(const SmallCinParams p) {
+    MSR_SATURATING_CONVERSIONS();
     constexpr int QUADS = COUT / 4;          // threads per pixel group
     constexpr int GRP = 256 / QUADS;         // pixel groups per block pass
     const int q = threadIdx.x % QUADS;
@@ -97,6 +98,7 @@ __global__ void __launch_bounds__(256) conv_smallcin_kernel(const SmallCinParams
 // multiplications and additions in the same order as conv_smallcin_kernel: bit-identical output.
 template <int COUT>
 __global__ void __launch_bounds__(256) conv_smallcin_tiled_kernel(const SmallCinParams p) {
+    MSR_SATURATING_CONVERSIONS();
     constexpr int QUADS = COUT / 4, GRP = 256 / QUADS, PX = 4, WMAX = 2 * PX + 1, WW = 34;
     __shared__ float2 win[WW * WW];
     const int tiles = p.Hout >> 4;

@@ -480,6 +480,59 @@ def test_spade_layer_resident_kernel(ctx, B, S, r, C, shift):
         float(full[0][:, -1].abs().max()) == 0 and float(full[2][:, :, 0].abs().max()) == 0        # the border stays zero
 
 
+def test_f16c_saturation_regimes(ctx):
+    """What the f16c path does with activations outside the pieces' ranges (kernels.h msr_store_f16c4_dev):
+      |a| <= 448            all three terms live: per-product error ~2^-15 (the parity regime; every activation of the
+                            BASELINE shapes with Keras-default weights is inside it: max |a| ~ 40);
+      448 < |a| <= 65504    the e4m3 piece h8 saturates at 448 (and, beyond ~900, l8 = e4m3((a - hi) * 2^11) does too), so the
+                            cross terms are short: the conv degrades to ~2^-11 per product (the fp16 rounding of weight and
+                            activation) — stated here as <= 1e-3 of the output range;
+      |a| > 65504           the producer clamps to +-65504: finite and wrong (fp32 would carry on); never an infinity.
+    Consumer side (conv_igemm_f16c_sw through msr_op_conv3x3_f16c) on host-built images, producer side (conv_gb_resident's
+    epilogue) through a gamma bias that pushes the SPADE output past both limits."""
+    from moonsuperresolution_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(77)
+    B, r, cin, cout = 2, 32, 128, 128
+    x0 = torch.randn((B, r, r, cin), generator=g).cuda()
+    w = (torch.randn((3, 3, cin, cout), generator=g) / np.sqrt(9 * cin)).cuda()
+    b = torch.zeros(cout).cuda()
+    wimg, wexp, _ = ops.f16c_weight_image(ops.kernel_layout(w))
+    errs = {}
+    for name, scale in (("inside", 100.0), ("h8 saturated", 1.0e4)):        # max |a| ~ 4.5 sigma: 450 -> inside needs 448
+        x = (x0 * scale / 4.6).clamp(-scale, scale)
+        ximg, _ = ops.f16c_activation_image(ops.pad_nhwc(x))
+        y = ops.conv3x3_f16c(ctx, ximg, wimg, wexp, b, r).cpu().numpy()
+        errs[name] = rel_linf(y, ref_conv(x, w, b, 1).numpy())
+    print("f16c conv, activations inside the pieces' range / beyond 448:", errs)
+    assert errs["inside"] <= 1e-4 and errs["h8 saturated"] <= 1e-3, errs
+    assert errs["h8 saturated"] > errs["inside"]                           # the regime exists: that is what is documented
+    # producer: SPADE output = lrelu(gamma * normalised + beta) with gamma bias 3e4 and normalised ~ +-3 -> |a| up to ~9e4
+    Bp, S, rr, C = 2, 128, 32, 64
+    src = (torch.rand((Bp, S, S, 2), generator=g) - 0.5).cuda()
+    we = (torch.randn((3, 3, 2, 128), generator=g) / 3).cuda()
+    be = (0.1 * torch.randn(128, generator=g)).cuda()
+    wg = (torch.randn((3, 3, 128, C), generator=g) / 34).cuda()
+    wb_ = (torch.randn((3, 3, 128, C), generator=g) / 34).cuda()
+    bg, bb = torch.full((C,), 3.0e4).cuda(), torch.randn(C, generator=g).cuda()
+    xx = torch.randn((Bp, rr, rr, C), generator=g).cuda()
+    mean = xx.mean((0, 1, 2)).contiguous()
+    std = torch.sqrt(xx.var((0, 1, 2), unbiased=False) + 1e-5).contiguous()
+    wl, bias = ops.spade_layout(wg, wb_, bg, bb)
+    y = ops.spade_gbr(ctx, src, we, be, ops.gbr_weight_image(wl), bias, rr, xx, 0, mean, std)
+    hi, h8, lo8 = (t.cpu()[:, 1:-1, 1:-1] for t in ops.f16c_decode(y))
+    f = S // rr
+    e = torch.relu(ref_conv(src[:, f // 2::f, f // 2::f][:, :rr, :rr], we, be, 1))
+    v = ref_conv(e, wg, bg, 1) * ((xx.double().cpu() - mean.double().cpu()) / std.double().cpu()) + ref_conv(e, wb_, bb, 1)
+    want = torch.where(v >= 0, v, 0.2 * v)
+    assert float(want.abs().max()) > 65504 and torch.isfinite(hi).all() and torch.isfinite(h8).all() and torch.isfinite(lo8).all()
+    over = want.abs() > 65504
+    assert over.any() and float((hi[over].abs() - 65504).abs().max()) == 0      # clamped, with the sign kept
+    assert bool((torch.sign(hi[over]) == torch.sign(want[over])).all())
+    mid = (want.abs() > 448) & (want.abs() < 6.0e4)
+    assert float((h8[mid].abs() - 448).abs().max()) == 0                        # the e4m3 piece saturates at 448
+    assert float(((hi + lo8)[mid] - want[mid]).abs().max() / 6.0e4) <= 2.0 ** -11   # hi alone: fp16's 11 bits
+
+
 def test_head_kernel_known_answers(ctx):
     """Kernel-level KAT of the head on the HIP side (the oracle side: tests/test_oracle_generator.py):
       * delta image -> the 1-before / 2-after SAME padding of Conv2D(1, 4) after UpSampling2D(2) (networks.py:55-56): a one
