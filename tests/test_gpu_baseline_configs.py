@@ -115,7 +115,7 @@ def test_f16c_with_the_opt_in_fp6_cross_pieces_matches_oracle():
 
 
 @pytest.mark.parametrize("switch", ["MSR_GBR=0", "MSR_TILE_WALK=0", "MSR_PP_KSPLIT=0", "MSR_F16C_KSPLIT=0", "MSR_F16C_SW=0",
-                                    "MSR_F16C_SW=2"])
+                                    "MSR_F16C_SW=2", "MSR_FUSE_MOMENTS=0", "MSR_SMALLCIN_TILED=0"])
 def test_f16c_parity_under_every_documented_kernel_switch(switch):
     """The behaviour-changing environment switches of the library (each read once per process: A/B dispatch of the conv kernels,
     tile walk, K ranges) must all leave the default mode inside the parity bar: GauGAN(256, 16) against the oracle in a child
