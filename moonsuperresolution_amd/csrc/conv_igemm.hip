@@ -1684,6 +1684,7 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(const ConvParams p
         float4 a = *reinterpret_cast<const float4*>(pp);
         float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (EPI == EPI_SPADE) bsum = *reinterpret_cast<const float4*>(pp + 32);
+#pragma unroll 8      // the K ranges' loads in flight together, the additions in range order
         for (int k = 1; k < p.ksplit; ++k) {
             const float4 t = *reinterpret_cast<const float4*>(pp + k * pstride);
             a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;

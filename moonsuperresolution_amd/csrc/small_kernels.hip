@@ -350,13 +350,16 @@ __global__ void __launch_bounds__(256) splitk_epilogue_mom_kernel(const ConvPara
     const int p1 = min(P, p0 + chunk_px);
     const size_t pstride = (size_t)p.B * p.Hout * p.Wout * p.N;
     auto load = [&](int pl, int q) {
-        const long pix = (long)g * P + pl;
-        const int x = (int)(pix % p.Wout);
-        const int y = (int)((pix / p.Wout) % p.Hout);
-        const int b = (int)(pix / ((long)p.Wout * p.Hout));
+        // 32-bit pixel arithmetic (B * Hout * Wout < 2^31, checked by the launcher): the 64-bit divisions cost more than the loads
+        const int pix = g * P + pl;
+        const int x = pix % p.Wout;
+        const int yb = pix / p.Wout;
+        const int y = yb % p.Hout, b = yb / p.Hout;
         const int c = q * 4;
         const float* pp = p.partial + (size_t)pix * p.N + c;
         float4 a = *reinterpret_cast<const float4*>(pp);
+        // the K ranges are added in range order (the plain epilogue's order); 8 loads in flight instead of one
+#pragma unroll 8
         for (int k = 1; k < p.ksplit; ++k) {
             const float4 t = *reinterpret_cast<const float4*>(pp + k * pstride);
             a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
@@ -379,7 +382,8 @@ __global__ void __launch_bounds__(256) splitk_epilogue_mom_kernel(const ConvPara
 
 hipError_t launch_splitk_epilogue_mom(const ConvParams& p, int epi, hipStream_t s) {
     const int G = p.mom_G > 1 ? p.B : 1;
-    if ((epi != EPI_BIAS && epi != EPI_RES) || p.N % 32 || !p.mom_partial) return hipErrorInvalidValue;
+    if ((epi != EPI_BIAS && epi != EPI_RES) || p.N % 32 || !p.mom_partial || (long)p.B * p.Hout * p.Wout >= (1L << 31))
+        return hipErrorInvalidValue;
     const int P = (G > 1 ? 1 : p.B) * p.Hout * p.Wout;
     const int chunks = moments_chunks(G, P);
     const dim3 grid(chunks, G, moments_channel_blocks(G, P, p.N));
@@ -528,6 +532,19 @@ __global__ void __launch_bounds__(256) dense_final_kernel(const float* __restric
     }
 }
 
+// few K chunks (the generator's Dense: 8 at S = 512), many outputs: one thread per output, chunks added in order
+// (dense_final_kernel's 16 outputs per workgroup meant 32768 workgroups for 0.5 M outputs: 14.6 us for 16 MB)
+__global__ void __launch_bounds__(256) dense_final_flat_kernel(const float* __restrict__ partial,
+                                                               const float* __restrict__ bias, float* __restrict__ y,
+                                                               int splits, int B, int N) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * N) return;
+    float s = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < splits; ++k) s += partial[(size_t)k * B * N + i];
+    y[i] = s + (bias ? bias[i % N] : 0.f);
+}
+
 hipError_t launch_dense(const float* x, const float* W, const float* bias, float* partial, float* y, int B, int K,
                         int N, hipStream_t s) {
     if (B > DENSE_MAXB || N % 4) return hipErrorInvalidValue;
@@ -539,7 +556,8 @@ hipError_t launch_dense(const float* x, const float* W, const float* bias, float
     else if (B <= 4) dense_partial_kernel<4><<<grid, 128, 0, s>>>(x, W, partial, B, K, N, kch);
     else if (B <= 8) dense_partial_kernel<8><<<grid, 128, 0, s>>>(x, W, partial, B, K, N, kch);
     else dense_partial_kernel<16><<<grid, 128, 0, s>>>(x, W, partial, B, K, N, kch);
-    dense_final_kernel<<<(B * N + 15) / 16, 256, 0, s>>>(partial, bias, y, splits, B, N);
+    if (splits <= 16 && (long)B * N >= 65536) dense_final_flat_kernel<<<(B * N + 255) / 256, 256, 0, s>>>(partial, bias, y, splits, B, N);
+    else dense_final_kernel<<<(B * N + 15) / 16, 256, 0, s>>>(partial, bias, y, splits, B, N);
     return hipGetLastError();
 }
 
