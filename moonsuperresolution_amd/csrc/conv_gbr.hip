@@ -294,11 +294,15 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
            clobbered inputs (measured: the h6 piece came out partly wrong, tools/gpu_debug_gbr.py) */ \
         if ((PAIR) == 1) GB_STAMP3()                                                             \
         i32x6 h6, l6;                                                                            \
+        if constexpr (!NOX) {                                                                    \
         asm volatile("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(h6) : "v"(va), "v"(vb), "v"(s_hi)); \
         asm volatile("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(l6) : "v"(la), "v"(lb), "v"(s_lo)); \
+        }                                                                                        \
         if (live) {                                                                              \
             char* const fp = smem + (wq * 4 * PH + hp) * 16;                                     \
             _Pragma("unroll") for (int pc = 0; pc < 4; ++pc) *reinterpret_cast<f16x8*>(fp + pc * PH * 16) = hv[pc]; \
+        }                                                                                        \
+        if (!NOX && live) {       /* NOX: the fp6 pieces and their scales are not read: not made */ \
             char* const xpa = smem + GB_F_BYTES + (wq * 2 * PH + hp) * 16;                       \
             char* const xpb = smem + GB_F_BYTES + GB_XA_BYTES + (wq * 2 * PH + hp) * 8;          \
             *reinterpret_cast<i32x4*>(xpa) = i32x4{h6[0], h6[1], h6[2], h6[3]};                  \

@@ -247,6 +247,7 @@ conv_igemm_f16c_sw(const ConvParams p, const SwGeom g) {
     // VALU instructions in an f16 phase) instead of held in 22 registers.
     const int hp0 = tid >> 3, hseg = tid & 7;
     const int h_l0 = hp0 * BKP + hseg * 4;
+    const bool h_live = !NOX || hseg < 4;          // NOX: only the fp16 half of a chunk row (bytes 0..63) is staged
 #define SW_HPIX(q) ((q) < 10 ? hp0 + 32 * (q) : min(hp0 + 32 * (q), HP - 1))
 #define SW_HGOFF(q) ((((SW_HPIX(q) * 3641) >> 16) * p.in_py + (SW_HPIX(q) - ((SW_HPIX(q) * 3641) >> 16) * HW) * p.Cin + hseg * 4) * 4)
 #define SW_HLOFF(q) ((q) < 10 ? h_l0 + 32 * (q) * BKP : SW_HPIX(q) * BKP + hseg * 4)
@@ -326,12 +327,16 @@ conv_igemm_f16c_sw(const ConvParams p, const SwGeom g) {
         const unsigned hs_ = (T) < 9 ? h_cur + BKC * 4 : h_after;                                \
         if constexpr (t_ >= HD && t_ <= 5 + HD) {                                                \
             constexpr int q_ = 2 * (t_ - HD);                                                    \
+            if (h_live) {                                                                        \
             *reinterpret_cast<i32x4*>(w_ + SW_HLOFF(q_)) = rh[(t_ - HD) % HD][0];                \
             if constexpr (q_ + 1 < H_ITEMS) *reinterpret_cast<i32x4*>(w_ + SW_HLOFF((q_ + 1) % H_ITEMS)) = rh[(t_ - HD) % HD][1]; \
+            }                                                                                    \
         }                                                                                        \
         if constexpr (t_ <= 5) {                                                                 \
+            if (h_live) {                                                                        \
             rh[t_ % HD][0] = SW_BUFLD(rs_in, SW_HGOFF(2 * t_), hs_);                             \
             if constexpr (2 * t_ + 1 < H_ITEMS) rh[t_ % HD][1] = SW_BUFLD(rs_in, SW_HGOFF((2 * t_ + 1) % H_ITEMS), hs_); \
+            }                                                                                    \
         }                                                                                        \
     }
     // Diagnostic build only (-DMSR_SW_STAMPS=1: one s_memtime stamp per tap pair, =2: per phase; tools/gpu_sw_stamps.py):
@@ -442,9 +447,9 @@ conv_igemm_f16c_sw(const ConvParams p, const SwGeom g) {
     {
         i32x4 t[H_ITEMS];
 #pragma unroll
-        for (int q = 0; q < H_ITEMS; ++q) t[q] = SW_BUFLD(rs_in, SW_HGOFF(q), h_tile);
+        for (int q = 0; q < H_ITEMS; ++q) if (h_live) t[q] = SW_BUFLD(rs_in, SW_HGOFF(q), h_tile);
 #pragma unroll
-        for (int q = 0; q < H_ITEMS; ++q) *reinterpret_cast<i32x4*>(smem + SW_HLOFF(q)) = t[q];
+        for (int q = 0; q < H_ITEMS; ++q) if (h_live) *reinterpret_cast<i32x4*>(smem + SW_HLOFF(q)) = t[q];
     }
     {
         const unsigned w_cur = w_tile, w_after = w_tile;
