@@ -761,6 +761,12 @@ int msr_load_weight(msr_handle* h, const char* name_c, const float* host, const 
                name == "gen.dense.bias" || (name.find(".conv_") != std::string::npos && ends_with(name, ".bias") &&
                                             name.find("spade") == std::string::npos)) {
         rc = upload(h, name, host, count);   // used in the reference layout
+        if (!rc && ends_with(name, ".conv.kernel") && name.find(".spade_") != std::string::npos) {
+            // conv_gb_resident multiplies the mask embedding on the fp16 MFMA: its A operands (three fp16 terms per product)
+            std::vector<float> e16(4096);
+            conv_gbr_embed_image(host, e16.data());
+            rc = upload(h, name + ".e16", e16.data(), e16.size());
+        }
     } else if (name == "enc.mean.kernel" || name == "enc.variance.kernel") {
         // concatenate the two heads into one [K, 2L] matrix so the flatten is streamed once
         float* d = nullptr;
@@ -1073,6 +1079,7 @@ int plan_spade(msr_handle* h) {
                 Op g; g.type = OP_GBR; g.src_is_input = true;
                 GbrParams& q = g.gbr;
                 snprintf(k, sizeof k, "gen.rb%d.spade_%d.conv.kernel", i, j); q.we = need(k);
+                snprintf(k, sizeof k, "gen.rb%d.spade_%d.conv.kernel.e16", i, j); q.we16 = need(k);
                 snprintf(k, sizeof k, "gen.rb%d.spade_%d.conv.bias", i, j); q.be = need(k);
                 q.S = S; q.f = S / r; q.o = (S / r) / 2;
                 snprintf(k, sizeof k, "gen.rb%d.spade_%d.gb.kernel", i, j); q.wt = need(k);
@@ -1757,7 +1764,18 @@ int msr_op_spade_gbr(msr_handle* h, const float* src_dev, int32_t S, const float
     q.out_split = 4; q.slope = 0.2f; q.B = B; q.r = r; q.N = N;
     int ranges = conv_gbr_ranges(B, r, N);       // the planner's split; a layer it would not take runs one item per pixel tile
     if (ranges < 1) ranges = 1;
-    hipError_t e = launch_conv_gbr(q, ranges, (hipStream_t)stream);
+    // the embedding kernel as fp16 MFMA operands (msr_load_weight builds this image once per layer; this test entry per call)
+    std::vector<float> we_host(9 * 2 * 128), e16(4096);
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+    HIPCHK(h, hipMemcpy(we_host.data(), we_dev, we_host.size() * sizeof(float), hipMemcpyDeviceToHost));
+    conv_gbr_embed_image(we_host.data(), e16.data());
+    float* e16_dev = nullptr;
+    HIPCHK(h, hipMalloc(&e16_dev, e16.size() * sizeof(float)));
+    hipError_t e = hipMemcpy(e16_dev, e16.data(), e16.size() * sizeof(float), hipMemcpyHostToDevice);
+    q.we16 = e16_dev;
+    if (e == hipSuccess) e = launch_conv_gbr(q, ranges, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    hipFree(e16_dev);
     if (e != hipSuccess) return fail(h, MSR_ERR_INVALID, "conv_gb_resident launch rejected: %s", hipGetErrorString(e));
     return MSR_OK;
 }

@@ -167,10 +167,11 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
         int lane1 = lane;
         asm volatile("" : "+v"(lane1));
         const int h = lane1 >> 5;
-        float ewt[9];
+        i32x4 ewt[4];                          // A operands of the four f16 MFMAs (GbrParams.we16: [chunk][instr][lane] x 16 B)
         f32x16 ebias;
 #pragma unroll
-        for (int sT = 0; sT < 9; ++sT) ewt[sT] = p.we[(2 * sT + h) * 128 + 32 * wq + (lane1 & 31)];
+        for (int j = 0; j < 4; ++j)
+            ewt[j] = *reinterpret_cast<const i32x4*>(reinterpret_cast<const char*>(p.we16) + (((wq * 4 + j) * 64 + lane1) << 4));
 #pragma unroll
         for (int t = 0; t < 16; t += 4) {
             const float4 b4 = *reinterpret_cast<const float4*>(p.be + 32 * wq + 8 * (t >> 2) + 4 * h);
@@ -190,16 +191,29 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
         __syncthreads();                       // the previous item's sweep has left the planes and the stage lines
         GB_STAMP2()
         // ================= phase 1a: the patch into LDS ========================================================================
-        {
-            float2* const patch = reinterpret_cast<float2*>(smem + GB_STAGE_OFF);
-            patch[tid] = pv[0];
-            if (tid + 256 < 400) patch[tid + 256] = pv[1];
+        {   // patch[kind][pixel]: one dword = the two mask channels as fp16; kind 0 = hi = f16(v), 1 = lo = f16(v - hi)
+            unsigned* const patch = reinterpret_cast<unsigned*>(smem + GB_STAGE_OFF);
+            typedef _Float16 h2p __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int q = tid + 256 * u;
+                const h2p hi2 = {(_Float16)pv[u].x, (_Float16)pv[u].y};
+                const h2p lo2 = {(_Float16)(pv[u].x - (float)hi2[0]), (_Float16)(pv[u].y - (float)hi2[1])};
+                if (q < 400) {
+                    patch[q] = __builtin_bit_cast(unsigned, hi2);
+                    patch[400 + q] = __builtin_bit_cast(unsigned, lo2);
+                }
+            }
         }
         __syncthreads();
         GB_STAMP2()
         // ================= phase 1b: embedding halo -> F / X / SC planes; wave = chunk ======================================
-        // E[ch][pixel] = bias[ch] + sum_k We[k][ch] * mask[pixel][k] on v_mfma_f32_32x32x2_f32 (exact fp32: the fmaf chain in
-        // k = (ky, kx, c) order, bias first), k = 2 * tap + c: 9 MFMAs per tile of 32 channels x 32 pixels.  A lane of the
+        // E[ch][pixel] = bias[ch] + sum_k We[k][ch] * mask[pixel][k], k = 2 * tap + c (18 terms), as THREE fp16 products per term
+        // — w_hi x_hi + w_hi x_lo + w_lo x_hi with hi = f16(v), lo = f16(v - hi): 22 of fp32's 24 bits, products exact, fp32
+        // accumulation, f16 denormals honoured (tools/gpu_diag_mfma_f16.hip) — on v_mfma_f32_32x32x16_f16: the 54 products are
+        // packed into the 64 K slots of FOUR instructions per tile of 32 channels x 32 pixels (128 matrix cycles; until round
+        // 3's last step the exact-fp32 v_mfma_f32_32x32x2_f32 took 9 x 64 and, sharing the vector ALU's issue, did not overlap the
+        // conversions).  Mask values beyond fp16's range (|v| > 65504; the tiler hands over [-0.5, 0.5]) saturate.  A lane of the
         // 32 x 32 result holds HALF of a pixel's 32 channels (rows 8q + 4h + r, h = lane >> 5); two tiles (pixels A, B) and
         // one v_permlane32_swap per register leave ALL 32 channels of pixel 64 * pair + lane in the lane, which is what the
         // fp6 converter wants (v_cvt_scalef32_2xpk16_fp6_f32: 32 values -> one 24-byte k-block, element 2t = a[t],
@@ -208,31 +222,40 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
         // Software pipeline: the 18 MFMAs of pair p + 1 are issued before the conversion of pair p (an MFMA holds the vector
         // issue for 8 of its 64 cycles: the ~200 VALU instructions of a conversion run beside them).
         {
-            const float* const patch = reinterpret_cast<const float*>(smem + GB_STAGE_OFF);
-            // B operands (patch values) of tile `tile_` (pixels 32 tile + (lane & 31), clamped): 9 LDS reads
+            const unsigned* const patch = reinterpret_cast<const unsigned*>(smem + GB_STAGE_OFF);
+            // K slots of the four MFMAs: pair P = 8 j + 4 h + u (instr j, k-half h = lane >> 5, dword u of the lane's 8 halves)
+            // is term P / 9, tap P % 9 for P < 27 (zero weights beyond): its patch dword sits at kind * 400 + dy * 20 + dx
+#define GB_EMB_POFF(P) ((P) < 27 ? (((P) / 9 == 1) ? 400 : 0) + (((P) % 9) / 3) * 20 + ((P) % 9) % 3 : 0)
+            int poff[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) poff[4 * j + u] = h ? GB_EMB_POFF(8 * j + 4 + u) : GB_EMB_POFF(8 * j + u);
+            // B operands (patch values) of tile `tile_` (pixels 32 tile + (lane & 31), clamped): 16 LDS reads
 #define GB_EMB_LOADB(bv_, tile_)                                                                  \
     {                                                                                            \
         int hq_ = 32 * (tile_) + (lane1 & 31);                                                    \
         hq_ = hq_ < HP ? hq_ : HP - 1;                                                           \
         const int hy_ = (hq_ * 3641) >> 16;              /* / 18 for 0 <= hq < 324 */            \
         const int hx_ = hq_ - hy_ * HW;                                                          \
-        const float* const pp_ = patch + ((hy_ * 20 + hx_) * 2 + h);                             \
-        _Pragma("unroll") for (int sT = 0; sT < 9; ++sT) bv_[sT] = pp_[((sT / 3) * 20 + sT % 3) * 2]; \
+        const unsigned* const pp_ = patch + (hy_ * 20 + hx_);                                    \
+        _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) bv_[q_] = pp_[poff[q_]];               \
     }
+#define GB_EMB_B(bv_, J) __builtin_bit_cast(f16x8, i32x4{(int)bv_[4 * (J)], (int)bv_[4 * (J) + 1], (int)bv_[4 * (J) + 2], (int)bv_[4 * (J) + 3]})
             // the K-th of the 18 MFMAs of the NEXT pair (tile A step K >> 1 for even K, tile B for odd K), issued between the
             // conversion steps of the current pair: an MFMA occupies the matrix pipe for 64 cycles and the vector issue for a
             // few, so ~12 VALU instructions per MFMA run beside it
 #define GB_EMB_MFMA(K)                                                                            \
     {                                                                                            \
-        if ((K) & 1) { if (nextB) nB = __builtin_amdgcn_mfma_f32_32x32x2f32(ewt[(K) >> 1], bvB[(K) >> 1], (K) >> 1 ? nB : ebias, 0, 0, 0); } \
-        else if (nextA) nA = __builtin_amdgcn_mfma_f32_32x32x2f32(ewt[(K) >> 1], bvA[(K) >> 1], (K) >> 1 ? nA : ebias, 0, 0, 0); \
+        if ((K) & 1) { if (nextB) nB = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ewt[(K) >> 1]), GB_EMB_B(bvB, (K) >> 1), (K) >> 1 ? nB : ebias, 0, 0, 0); } \
+        else if (nextA) nA = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ewt[(K) >> 1]), GB_EMB_B(bvA, (K) >> 1), (K) >> 1 ? nA : ebias, 0, 0, 0); \
     }
             // One pair: conversion of (tA, tB) = pixels 64 PAIR + lane, interleaved with the MFMAs of pair PAIR + 1 into (nA, nB).
             // lane l < 32 gets tile A's two channel halves of its pixel, l >= 32 tile B's (v_permlane32_swap).
 #define GB_EMB_PAIR(PAIR)                                                                         \
     {                                                                                            \
         constexpr bool nextA = (PAIR) + 1 <= 5, nextB = (PAIR) + 1 <= 4;                          \
-        float bvA[9], bvB[9];                                                                    \
+        unsigned bvA[16], bvB[16];                                                               \
         if (nextA) GB_EMB_LOADB(bvA, 2 * ((PAIR) + 1))                                            \
         if (nextB) GB_EMB_LOADB(bvB, 2 * ((PAIR) + 1) + 1)                                        \
         __builtin_amdgcn_sched_barrier(0);                                                       \
@@ -268,7 +291,7 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
             lo[t] = __builtin_amdgcn_fmed3f(lo[t], 0.f, top);                                    \
             hi[t] = __builtin_amdgcn_fmed3f(hi[t], 0.f, top);                                    \
             amax = fmaxf(amax, fmaxf(lo[t], hi[t]));                                             \
-            if (t < 10) GB_EMB_MFMA(t)                                                           \
+            if (t < 8 && !(t & 1)) GB_EMB_MFMA(t >> 1)          /* the next pair's 8 MFMAs (32 cycles each) beside the conversion */ \
             __builtin_amdgcn_sched_barrier(0);                                                   \
         }                                                                                        \
         if ((PAIR) == 1) GB_STAMP3()                                                             \
@@ -286,7 +309,7 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
             vb[t] = hi[t];                                                                       \
             la[t] = lo[t] - (float)pk[0];                                                        \
             lb[t] = hi[t] - (float)pk[1];                                                        \
-            if (t < 8) GB_EMB_MFMA(10 + t)                                                       \
+            if (t < 8 && !(t & 1)) GB_EMB_MFMA(4 + (t >> 1))                                     \
             __builtin_amdgcn_sched_barrier(0);                                                   \
         }                                                                                        \
         /* v_cvt_scalef32_2xpk16_fp6_f32 through inline asm with an EARLY-CLOBBER result: the builtin lets hipcc 7.2 put \
@@ -323,15 +346,15 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
     }
             f32x16 tA, tB, nA, nB;
             {   // pair 0's own MFMAs (nothing to hide them behind)
-                float bvA[9], bvB[9];
+                unsigned bvA[16], bvB[16];
                 GB_EMB_LOADB(bvA, 0)
                 GB_EMB_LOADB(bvB, 1)
                 tA = ebias;
                 tB = ebias;
 #pragma unroll
-                for (int sT = 0; sT < 9; ++sT) {
-                    tA = __builtin_amdgcn_mfma_f32_32x32x2f32(ewt[sT], bvA[sT], tA, 0, 0, 0);
-                    tB = __builtin_amdgcn_mfma_f32_32x32x2f32(ewt[sT], bvB[sT], tB, 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    tA = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ewt[j]), GB_EMB_B(bvA, j), tA, 0, 0, 0);
+                    tB = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ewt[j]), GB_EMB_B(bvB, j), tB, 0, 0, 0);
                 }
                 nA = tA;
                 nB = tB;
@@ -339,6 +362,8 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
             GB_EMB_PAIR(0) GB_EMB_PAIR(1) GB_EMB_PAIR(2) GB_EMB_PAIR(3) GB_EMB_PAIR(4) GB_EMB_PAIR(5)
             GB_STAMP2()
 #undef GB_EMB_LOADB
+#undef GB_EMB_POFF
+#undef GB_EMB_B
 #undef GB_EMB_MFMA
 #undef GB_EMB_PAIR
         }
@@ -562,6 +587,28 @@ conv_gb_resident(const GbrParams p, const GbrGeom g) {
 #undef GB_BODY
 }
 
+void conv_gbr_embed_image(const float* we, float* out4096) {
+    unsigned short* o = reinterpret_cast<unsigned short*>(out4096);
+    for (int wq = 0; wq < 4; ++wq)
+        for (int j = 0; j < 4; ++j)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int kh = lane >> 5, ch = 32 * wq + (lane & 31);
+                for (int u = 0; u < 4; ++u) {
+                    const int P = 8 * j + 4 * kh + u;
+                    for (int c = 0; c < 2; ++c) {
+                        unsigned short bits = 0;
+                        if (P < 27) {
+                            const float w = we[((P % 9) * 2 + c) * 128 + ch];
+                            const _Float16 hi = (_Float16)w;
+                            const _Float16 lo = (_Float16)(w - (float)hi);
+                            bits = __builtin_bit_cast(unsigned short, P / 9 == 2 ? lo : hi);
+                        }
+                        o[(((wq * 4 + j) * 64 + lane) * 8) + 2 * u + c] = bits;
+                    }
+                }
+            }
+}
+
 hipError_t conv_gbr_init() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gb_resident<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)GB_LDS);
@@ -584,7 +631,7 @@ int conv_gbr_ranges(int B, int r, int N) {
 }
 
 hipError_t launch_conv_gbr(const GbrParams& p, int ranges, hipStream_t s) {
-    if (ranges < 1 || p.r < 16 || (p.r & (p.r - 1)) || p.N % 128 || (p.N / 128) % ranges || p.out_split != 4 || !p.src || !p.we || !p.be || !p.wt || !p.aux || !p.mean || !p.stdv || !p.out)
+    if (ranges < 1 || p.r < 16 || (p.r & (p.r - 1)) || p.N % 128 || (p.N / 128) % ranges || p.out_split != 4 || !p.src || !p.we16 || !p.be || !p.wt || !p.aux || !p.mean || !p.stdv || !p.out)
         return hipErrorInvalidValue;
     if (p.f < 1 || p.S != p.r * p.f || p.out_px % 32 || !(p.slope >= 0.f && p.slope <= 1.f)) return hipErrorInvalidValue;
     GbrGeom g;

@@ -295,7 +295,10 @@ void conv_walk_pick(int tiles_m, int tiles_n, int* walk_pb, int* walk_nb);
 // operand), the gamma|beta conv (spade.py:19-20) swept over it for all output channels, SPADE epilogue (spade.py:21-24).
 struct GbrParams {
     const float* src;       // [B, S, S, 2] the call's input
-    const float* we;        // mask-embedding conv kernel, HWIO [3][3][2][128]
+    const float* we;        // mask-embedding conv kernel, HWIO [3][3][2][128] (kept for reference / debugging; the kernel reads we16)
+    const void* we16;       // the same kernel as the A operands of phase 1's four v_mfma_f32_32x32x16_f16: [chunk 4][instr 4][lane 64]
+                            // x 8 fp16 (16 KB, conv_gbr_embed_image): K slot pair P = 8 j + 4 (lane >> 5) + u carries term P / 9
+                            // (0: w_hi for x_hi, 1: w_hi for x_lo, 2: w_lo for x_hi) of tap P % 9, both mask channels; P >= 27 zero
     const float* be;        // its bias [128]
     int S, f, o;            // source size; nearest resize to r x r: source index = t * f + o (f = S / r, o = f / 2)
     const float* wt;        // gamma|beta weights: PREC_F16C6 image of [9][N][128] (columns interleaved 32 gamma | 32 beta)
@@ -317,6 +320,8 @@ hipError_t conv_gbr_init();
 int conv_gbr_ranges(int B, int r, int N);
 // ranges: work items per pixel tile (a divisor of N / 128); the planner passes conv_gbr_ranges()
 hipError_t launch_conv_gbr(const GbrParams& p, int ranges, hipStream_t s);
+// host: HWIO [3][3][2][128] fp32 -> GbrParams.we16 image (4096 floats of storage)
+void conv_gbr_embed_image(const float* we_hwio, float* out4096);
 
 hipError_t conv_igemm_init();   // sets dynamic-LDS attributes once
 // conv_sw.hip: PREC_F16C whole-tile launches as one software-pipelined wave per SIMD.  launch_conv_igemm sends it the
