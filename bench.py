@@ -385,9 +385,15 @@ def run_workload(args, D: Dist, workload: str, precision: str, with_cpu: bool, w
             for _ in range(4):                               # first sighting eager, second captures, then replays
                 g1.forward_device(x1, out=o1)
             torch.cuda.current_stream().synchronize()
-            res["p50_ms_per_call_b1"] = statistics.median(b1_latencies(30))
-        res["p50_ms_per_call_b1_note"] = (f"GauGAN({S},1,256): median of 30 single calls, each synchronised, B = 1, launch "
-                                          "plan replayed as a HIP graph (msr_graph_enable); _eager = launched kernel by kernel")
+            res["p50_ms_per_call_b1_graph"] = statistics.median(b1_latencies(30))
+        # the figure a caller gets: the faster of the two launch modes (eager is the library's default; graph replay is opt-in
+        # and, with ~90 nodes of 5-60 us, costs more per node than the eager launches it replaces on this ROCm)
+        eager_faster = res["p50_ms_per_call_b1_eager"] <= res["p50_ms_per_call_b1_graph"]
+        res["p50_ms_per_call_b1"] = min(res["p50_ms_per_call_b1_eager"], res["p50_ms_per_call_b1_graph"])
+        res["p50_ms_per_call_b1_mode"] = "eager" if eager_faster else "graph"
+        res["p50_ms_per_call_b1_note"] = (f"GauGAN({S},1,256): median of 30 single calls, each synchronised, B = 1; _eager = launched "
+                                          "kernel by kernel (the default), _graph = launch plan replayed as a HIP graph "
+                                          "(msr_graph_enable); p50_ms_per_call_b1 = the faster mode, named in _mode")
         g1.close()
         del g1
         torch.cuda.empty_cache()
