@@ -1750,8 +1750,8 @@ int msr_op_spade_gbr(msr_handle* h, const float* src_dev, int32_t S, const float
                      const float* aux_dev, int32_t aux_shift, const float* mean_dev, const float* std_dev, void* stream) {
     if (!h) return MSR_ERR_INVALID;
     if (!src_dev || !we_dev || !be_dev || !wt_dev || !bias_dev || !out_dev || !aux_dev || !mean_dev || !std_dev || B < 1 ||
-        r < 32 || S < r || S % r || N % 128 || aux_shift < 0 || aux_shift > 1)
-        return fail(h, MSR_ERR_INVALID, "msr_op_spade_gbr: bad argument (r >= 32, S a multiple of r, N %% 128 == 0)");
+        r < 16 || S < r || S % r || N % 128 || aux_shift < 0 || aux_shift > 1)
+        return fail(h, MSR_ERR_INVALID, "msr_op_spade_gbr: bad argument (r >= 16, S a multiple of r, N %% 128 == 0)");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int C = N / 2, rx = r >> aux_shift;
     GbrParams q{};

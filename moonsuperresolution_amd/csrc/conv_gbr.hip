@@ -621,12 +621,14 @@ hipError_t conv_gbr_init() {
 // into the fewest ranges (a power of two) that give every CU an item.  Returns 0 if the layer is not one for this kernel.
 int conv_gbr_ranges(int B, int r, int N) {
     static const bool off = std::getenv("MSR_GBR") && std::atoi(std::getenv("MSR_GBR")) == 0;
-    if (off || r < 32 || (r & (r - 1)) || N % 128) return 0;
+    if (off || r < 16 || (r & (r - 1)) || N % 128) return 0;
     const int tiles_p = B * (r / 16) * (r / 16), tiles_n = N / 128;
     int ranges = 1;
     while (tiles_p * ranges < 256 && ranges * 2 <= tiles_n && tiles_n % (ranges * 2) == 0) ranges *= 2;
     if (tiles_p * ranges < 128) return 0;               // too few items even at one block per item
-    if (tiles_n / ranges < 2 && tiles_p * ranges < 256) return 0;
+    // one block per item on half of the CUs: still ahead of the ping-pong K ranges + split-K epilogue + embedding launch at
+    // r = 16 (26 against 38 us at B = 8), not at higher resolution where those launches fill the chip
+    if (tiles_n / ranges < 2 && tiles_p * ranges < 256 && r > 16) return 0;
     return ranges;
 }
 

@@ -440,7 +440,8 @@ def test_f16c_convs_under_the_other_kernel_dispatch(mode):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("B,S,r,C,shift", [(8, 128, 32, 1024, 1), (2, 256, 64, 128, 0), (8, 64, 64, 64, 1), (3, 512, 128, 64, 1)])
+@pytest.mark.parametrize("B,S,r,C,shift", [(8, 128, 32, 1024, 1), (2, 256, 64, 128, 0), (8, 64, 64, 64, 1), (3, 512, 128, 64, 1),
+                                           (8, 512, 16, 1024, 1)])
 def test_spade_layer_resident_kernel(ctx, B, S, r, C, shift):
     """conv_gb_resident (csrc/conv_gbr.hip): nearest resize + mask-embedding conv + ReLU + gamma|beta conv + SPADE epilogue in
     one launch, against the float64 chain of the same ops (spade.py:17-24, blocks.py:30-34).  The products are f16c6
