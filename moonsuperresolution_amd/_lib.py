@@ -144,6 +144,13 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C moonsuperresolution_amd/csrc`).  moonsuperresolution_amd has no CPU fallback.")
+    # torch first: its wheel bundles a HIP runtime, and whichever libamdhip64 is loaded first serves the whole process.  With
+    # this library (and so the system runtime) loaded before torch, msr_create found no device on the GPU pool's boxes
+    # (`python __graft_entry__.py smoke`, round 3) while torch in a fresh process saw it.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     for name, restype, argtypes in SYMBOLS:
         fn = getattr(lib, name)   # AttributeError if the ABI lost a symbol
