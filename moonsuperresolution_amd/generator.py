@@ -158,7 +158,10 @@ class Generator:
 
     def use_graph(self, on: bool = True) -> None:
         """Replay the launch plan as a HIP graph for calls that repeat their (input, noise, output) buffers
-        (msr_graph_enable): lower single-call latency; results identical."""
+        (msr_graph_enable); results identical.  Off by default, and measured in round 3 (bench.py, p50_ms_per_call_b1_graph
+        against _eager): on ROCm 7 the replay of this ~90-node plan is 0.07 ms SLOWER per B = 1 call than the eager
+        launches (1.96 against 1.89 ms) — the call is bound by ~5 us of dependent-launch latency per small kernel on the
+        GPU side, which a graph does not remove.  Kept for hosts whose launch path is slower than this pool's."""
         _lib.raise_for(self._lib, self._h, self._lib.msr_graph_enable(self._h, 1 if on else 0), "msr_graph_enable")
 
     def last_latent(self) -> np.ndarray:
